@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 ego-prior kernels.
+// Everything here is compiled with -ffp-contract=off: the hit test, the pixel-centre formula and the projection
+// must round exactly like the separate multiply/add sequences they restate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "egoprior.h"
+
+#define EP_TILE EGOPRIOR_TILE
+#define EP_K EGOPRIOR_MAX_K
+#define EP_WAVE 64
+
+namespace ep {
+
+// pytorch3d PixToNonSquareNdc (rasterization_utils): NDC coordinate of pixel-centre i on an axis of S1 pixels whose
+// other axis has S2 pixels.
+__device__ __forceinline__ float pix_to_ndc(int i, int S1, int S2) {
+    float range = 2.0f;
+    if (S1 > S2) range = ((float)S1 * range) / (float)S2;
+    const float offset = range / 2.0f;
+    return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+// Geometry of the raster shared by the binning and splat kernels (filled on the host).
+struct RasterGeom {
+    int H, W;
+    int tiles_x, tiles_y;
+    float half_range_x, half_range_y;  // NDC half extent of each axis
+    float inv_pitch_x, inv_pitch_y;    // pixels per NDC unit
+    float rad_px_x, rad_px_y;          // radius in pixels + conservative margin
+    float radius2;                     // float32(r) * float32(r)
+};
+
+// Conservative tile rectangle [tx0,tx1] x [ty0,ty1] touched by a disc; false when it misses the image (also for
+// non-finite coordinates and z < 0, which pytorch3d's rasterizer skips).
+__device__ __forceinline__ bool tile_range(const RasterGeom& g, float px, float py, float pz, int& tx0, int& tx1,
+                                           int& ty0, int& ty1) {
+    if (!(pz >= 0.0f)) return false;
+    const float cx = (g.half_range_x - px) * g.inv_pitch_x - 0.5f;
+    const float cy = (g.half_range_y - py) * g.inv_pitch_y - 0.5f;
+    const float lox = cx - g.rad_px_x, hix = cx + g.rad_px_x;
+    const float loy = cy - g.rad_px_y, hiy = cy + g.rad_px_y;
+    if (!(hix >= 0.0f) || !(lox <= (float)(g.W - 1)) || !(hiy >= 0.0f) || !(loy <= (float)(g.H - 1))) return false;
+    const int x0 = (int)floorf(fmaxf(lox, 0.0f));
+    const int x1 = (int)floorf(fminf(hix, (float)(g.W - 1)));
+    const int y0 = (int)floorf(fmaxf(loy, 0.0f));
+    const int y1 = (int)floorf(fminf(hiy, (float)(g.H - 1)));
+    tx0 = x0 / EP_TILE;
+    tx1 = x1 / EP_TILE;
+    ty0 = y0 / EP_TILE;
+    ty1 = y1 / EP_TILE;
+    return true;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (EP_WAVE - 1)); }
+
+// number of set bits of `m` strictly below this lane
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+}  // namespace ep

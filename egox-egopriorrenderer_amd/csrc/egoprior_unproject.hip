@@ -1,0 +1,615 @@
+// Exo-frame side of the path for gfx950: reliability mask, order-preserving compaction, fused unprojection
+// (rays * depth -> exo c2w -> float64 exo->world), render-entry filters and the mean-background reduction.
+//
+// All of these stream their inputs once: they are HBM-bound.  The 5x5 reliability stencil goes through an LDS tile
+// with a 2-pixel halo so each depth value is fetched from memory once per tile; everything else is a coalesced
+// element-wise pass.  Compaction keeps row-major order (block counts -> one-workgroup scan -> scatter) because the
+// reference's point indices -- the tie-breaker of the rasterizer -- are positions in the compacted arrays.
+#include "egoprior_common.h"
+#include "egoprior_host.h"
+
+namespace ep {
+
+// ------------------------------------------------------------------------------------------------------------------
+// 5x5 reliability test on an LDS tile (vipe/utils/depth.py:385-422)
+// ------------------------------------------------------------------------------------------------------------------
+// tile: clamped-coordinate copy of the depth around the block, row stride `ts`; (lx, ly) = position of the window's
+// top-left tap in the tile; (u, v) = pixel coordinates of the window centre.  Border taps outside the image are
+// ignored by max/min and count as zero in the 25-tap sum, which is always divided by 25.  The sum adds the taps one by
+// one, rows first, like ATen's CPU avg_pool2d.
+__device__ __forceinline__ bool reliable_at(const float* __restrict__ tile, int ts, int lx, int ly, int u, int v, int H,
+                                            int W) {
+    const bool interior = (u >= 2) && (v >= 2) && (u + 2 < W) && (v + 2 < H);
+    float mx = -INFINITY, mn = INFINITY, acc = 0.0f;
+    bool any_nan = false;
+    if (interior) {
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const float d = tile[(ly + kh) * ts + lx + kw];
+                any_nan |= (d != d);
+                mx = fmaxf(mx, d);
+                mn = fminf(mn, d);
+                acc = acc + d;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const int yy = v + kh - 2, xx = u + kw - 2;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float d = tile[(ly + kh) * ts + lx + kw];
+                    any_nan |= (d != d);
+                    mx = fmaxf(mx, d);
+                    mn = fminf(mn, d);
+                    acc = acc + d;
+                }
+            }
+        }
+    }
+    if (any_nan) return false;  // torch's max pool propagates NaN, so does the sum: ratio is NaN
+    const float centre = tile[(ly + 2) * ts + lx + 2];
+    const float mean = acc / 25.0f;
+    const float ratio = (mx - mn) / (mean + 1e-6f);
+    return (ratio < 0.1f) && (centre > 0.0f);
+}
+
+// cooperative clamped load of a (fw x fh) footprint whose top-left pixel is (x0, y0)
+__device__ __forceinline__ void load_footprint(float* __restrict__ tile, const float* __restrict__ depth, int H, int W,
+                                               int x0, int y0, int fw, int fh) {
+    for (int e = threadIdx.x; e < fw * fh; e += blockDim.x) {
+        const int ly = e / fw, lx = e - ly * fw;
+        int yy = y0 + ly, xx = x0 + lx;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        tile[e] = depth[(size_t)yy * W + xx];
+    }
+}
+
+#define EP_MASK_SX 32
+#define EP_MASK_SY 8
+
+// flags[j*Ws + i] = reliable(depth)[s*j, s*i] && select(mask[s*j, s*i]); one thread per sample, 32x8 samples per
+// block.  Dynamic LDS: (31*s+5)*(7*s+5) floats.
+__global__ void __launch_bounds__(256) k_reliable_flags(const float* __restrict__ depth,
+                                                        const uint8_t* __restrict__ mask, int H, int W, int s, int Hs,
+                                                        int Ws, int select, uint8_t* __restrict__ flags) {
+    extern __shared__ float tile[];
+    const int fw = (EP_MASK_SX - 1) * s + 5, fh = (EP_MASK_SY - 1) * s + 5;
+    const int i0 = blockIdx.x * EP_MASK_SX, j0 = blockIdx.y * EP_MASK_SY;
+    load_footprint(tile, depth, H, W, i0 * s - 2, j0 * s - 2, fw, fh);
+    __syncthreads();
+    const int li = threadIdx.x & (EP_MASK_SX - 1), lj = threadIdx.x / EP_MASK_SX;
+    const int i = i0 + li, j = j0 + lj;
+    if (i >= Ws || j >= Hs) return;
+    const int u = i * s, v = j * s;
+    bool ok = reliable_at(tile, fw, li * s, lj * s, u, v, H, W);
+    if (select != EGOPRIOR_SELECT_ALL) {
+        if (mask != nullptr) {
+            const uint8_t m = mask[(size_t)v * W + u];
+            ok = ok && ((select == EGOPRIOR_SELECT_STATIC) ? (m == 0) : (m != 0));
+        } else if (select == EGOPRIOR_SELECT_DYNAMIC) {
+            ok = false;
+        }
+    }
+    flags[(size_t)j * Ws + i] = ok ? 1 : 0;
+}
+
+// window taps straight from global memory (large subsample factors, where windows do not overlap)
+__global__ void __launch_bounds__(256) k_reliable_flags_direct(const float* __restrict__ depth,
+                                                               const uint8_t* __restrict__ mask, int H, int W, int s,
+                                                               int Hs, int Ws, int select,
+                                                               uint8_t* __restrict__ flags) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)Hs * Ws) return;
+    const int j = (int)(e / Ws), i = (int)(e - (int64_t)j * Ws);
+    const int u = i * s, v = j * s;
+    float win[25];
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+            int yy = v + kh - 2, xx = u + kw - 2;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            win[kh * 5 + kw] = depth[(size_t)yy * W + xx];
+        }
+    }
+    bool ok = reliable_at(win, 5, 0, 0, u, v, H, W);
+    if (select != EGOPRIOR_SELECT_ALL) {
+        if (mask != nullptr) {
+            const uint8_t m = mask[(size_t)v * W + u];
+            ok = ok && ((select == EGOPRIOR_SELECT_STATIC) ? (m == 0) : (m != 0));
+        } else if (select == EGOPRIOR_SELECT_DYNAMIC) {
+            ok = false;
+        }
+    }
+    flags[e] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// order-preserving compaction helpers: 1024 elements per block, 4 consecutive elements per thread
+// ------------------------------------------------------------------------------------------------------------------
+#define EP_CB 1024
+
+__global__ void __launch_bounds__(256) k_flag_block_count(const uint8_t* __restrict__ flags, int64_t n,
+                                                          uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t ws[4];
+    const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) c += flags[base + k] ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of block counts (one workgroup); writes the total to d_count and clears d_flags
+__global__ void __launch_bounds__(1024) k_block_scan(const uint32_t* __restrict__ block_count,
+                                                     uint32_t* __restrict__ block_offset, int n_blocks,
+                                                     int32_t* __restrict__ d_count, int32_t* __restrict__ d_flags) {
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int t = base + tid;
+        const uint32_t v = (t < n_blocks) ? block_count[t] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_sums[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w2 = 0; w2 < wid; ++w2) woff += wave_sums[w2];
+        const uint32_t carry = carry_s;
+        if (t < n_blocks) block_offset[t] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (d_count != nullptr) *d_count = (int32_t)carry_s;
+        if (d_flags != nullptr) *d_flags = 0;
+    }
+}
+
+// rank of each of this thread's 4 elements inside the block (exclusive), given its 4 flags
+__device__ __forceinline__ uint32_t block_exclusive_base(uint32_t thread_total, uint32_t* ws /*[4] shared*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t incl = thread_total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) ws[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w2 = 0; w2 < wid; ++w2) woff += ws[w2];
+    return woff + incl - thread_total;
+}
+
+__device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict__ d_flags) {
+    if (d_flags == nullptr) return;
+    if (__ballot(any_gt1) != 0ull && (threadIdx.x & 63) == 0) atomicOr(d_flags, 1);
+}
+
+// flags + block offsets -> compacted records: rays * depth, c2w (float32), exo->world (float64), colour bytes
+__global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_params p, int Hs, int Ws,
+                                                           const float* __restrict__ depth,
+                                                           const uint8_t* __restrict__ rgb,
+                                                           const uint8_t* __restrict__ flags,
+                                                           const uint32_t* __restrict__ block_offset,
+                                                           egoprior_point* __restrict__ out,
+                                                           double* __restrict__ out64, int32_t* __restrict__ d_flags) {
+    __shared__ uint32_t ws[4];
+    const int64_t n = (int64_t)Hs * Ws;
+    const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    bool f[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (base + k < n) && (flags[base + k] != 0);
+        c += f[k] ? 1u : 0u;
+    }
+    uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
+    bool gt1 = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!f[k]) continue;
+        const int64_t e = base + k;
+        const int j = (int)(e / Ws), i = (int)(e - (int64_t)j * Ws);
+        const int u = i * p.subsample, v = j * p.subsample;
+        const size_t pix = (size_t)v * p.W + u;
+        const float d = depth[pix];
+        const float X = ((float)u - p.cx) / p.fx;
+        const float Y = ((float)v - p.cy) / p.fy;
+        const float pcx = X * d, pcy = Y * d, pcz = 1.0f * d;
+        const float vx = ((p.c2w[0] * pcx + p.c2w[1] * pcy) + p.c2w[2] * pcz) + p.c2w[3];
+        const float vy = ((p.c2w[4] * pcx + p.c2w[5] * pcy) + p.c2w[6] * pcz) + p.c2w[7];
+        const float vz = ((p.c2w[8] * pcx + p.c2w[9] * pcy) + p.c2w[10] * pcz) + p.c2w[11];
+        const double wx = ((p.T[0] * (double)vx + p.T[1] * (double)vy) + p.T[2] * (double)vz) + p.T[3];
+        const double wy = ((p.T[4] * (double)vx + p.T[5] * (double)vy) + p.T[6] * (double)vz) + p.T[7];
+        const double wz = ((p.T[8] * (double)vx + p.T[9] * (double)vy) + p.T[10] * (double)vz) + p.T[11];
+        const uint32_t r = rgb[pix * 3 + 0], g = rgb[pix * 3 + 1], b = rgb[pix * 3 + 2];
+        gt1 |= (r > 1u) || (g > 1u) || (b > 1u);
+        egoprior_point q;
+        q.x = (float)wx;
+        q.y = (float)wy;
+        q.z = (float)wz;
+        q.rgba = r | (g << 8) | (b << 16);
+        out[slot] = q;
+        if (out64 != nullptr) {
+            out64[(size_t)slot * 3 + 0] = wx;
+            out64[(size_t)slot * 3 + 1] = wy;
+            out64[(size_t)slot * 3 + 2] = wz;
+        }
+        ++slot;
+    }
+    note_color_gt1(gt1, d_flags);
+}
+
+// render-entry filters: finite coordinates and |p| < 1e6 (float32 norm, ((x*x + y*y) + z*z) then sqrt)
+__global__ void __launch_bounds__(256) k_filter_flags(const float* __restrict__ xyz, int64_t n,
+                                                      uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    const bool finite = isfinite(x) && isfinite(y) && isfinite(z);
+    const float mag = sqrtf((x * x + y * y) + z * z);
+    flags[i] = (finite && (mag < 1e6f)) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_filter_scatter(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
+                                                        int64_t n, const uint8_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ block_offset,
+                                                        egoprior_point* __restrict__ out,
+                                                        int32_t* __restrict__ d_flags) {
+    __shared__ uint32_t ws[4];
+    const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    bool f[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f[k] = (base + k < n) && (flags[base + k] != 0);
+        c += f[k] ? 1u : 0u;
+    }
+    uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
+    bool gt1 = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!f[k]) continue;
+        const int64_t e = base + k;
+        const uint32_t r = rgb[e * 3 + 0], g = rgb[e * 3 + 1], b = rgb[e * 3 + 2];
+        gt1 |= (r > 1u) || (g > 1u) || (b > 1u);
+        egoprior_point q;
+        q.x = xyz[e * 3 + 0];
+        q.y = xyz[e * 3 + 1];
+        q.z = xyz[e * 3 + 2];
+        q.rgba = r | (g << 8) | (b << 16);
+        out[slot++] = q;
+    }
+    note_color_gt1(gt1, d_flags);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// mean background
+// ------------------------------------------------------------------------------------------------------------------
+// state planes: [(level*4 + q) * HW + pix], level 0..3, q = depth, r, g, b; plane 16 = int32 count.
+// One thread owns one pixel and walks the frames; per frame the block stages the 5x5 footprint of its 32x8 pixels in
+// LDS.  Sums follow ATen's CPU cascade order (see oracle.cascade_nansum): level 0 takes the terms one by one and is
+// flushed upward after every 16th term.
+__global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ state, const float* __restrict__ depth,
+                                                           const uint8_t* __restrict__ rgb,
+                                                           const uint8_t* __restrict__ mask, int F,
+                                                           long long first_index, int H, int W) {
+    __shared__ float tile[(EP_MASK_SX + 4) * (EP_MASK_SY + 4)];
+    __shared__ float lut[256];
+    const int fw = EP_MASK_SX + 4, fh = EP_MASK_SY + 4;
+    const int x0 = blockIdx.x * EP_MASK_SX, y0 = blockIdx.y * EP_MASK_SY;
+    const int lx = threadIdx.x & (EP_MASK_SX - 1), ly = threadIdx.x / EP_MASK_SX;
+    const int u = x0 + lx, v = y0 + ly;
+    const bool inside = (u < W) && (v < H);
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)v * W + u;
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;  // rgb = u8 / 255.0 (vipe/utils/io.py:250)
+
+    float acc[4][4];
+    int cnt = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[l][q] = inside ? state[(size_t)(l * 4 + q) * HW + pix] : 0.0f;
+    if (inside) cnt = ((const int*)state)[16 * HW + pix];
+
+    for (int f = 0; f < F; ++f) {
+        const float* dfr = depth + (size_t)f * HW;
+        __syncthreads();
+        load_footprint(tile, dfr, H, W, x0 - 2, y0 - 2, fw, fh);
+        __syncthreads();
+        if (inside) {
+            bool ok = reliable_at(tile, fw, lx, ly, u, v, H, W);
+            if (mask != nullptr) ok = ok && (mask[(size_t)f * HW + pix] == 0);
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            if (ok) {
+                const uint8_t* c = rgb + ((size_t)f * HW + pix) * 3;
+                t0 = tile[(ly + 2) * fw + lx + 2];
+                t1 = lut[c[0]];
+                t2 = lut[c[1]];
+                t3 = lut[c[2]];
+                ++cnt;
+            }
+            acc[0][0] = acc[0][0] + t0;
+            acc[0][1] = acc[0][1] + t1;
+            acc[0][2] = acc[0][2] + t2;
+            acc[0][3] = acc[0][3] + t3;
+            const long long i1 = first_index + f + 1;
+            if ((i1 & 15) == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[1][q] = acc[1][q] + acc[0][q];
+                    acc[0][q] = 0.0f;
+                }
+                if ((i1 & 0xF0) == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[2][q] = acc[2][q] + acc[1][q];
+                        acc[1][q] = 0.0f;
+                    }
+                    if ((i1 & 0xF00) == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[3][q] = acc[3][q] + acc[2][q];
+                            acc[2][q] = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (inside) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) state[(size_t)(l * 4 + q) * HW + pix] = acc[l][q];
+        ((int*)state)[16 * HW + pix] = cnt;
+    }
+}
+
+__device__ __forceinline__ float folded_sum(const float* __restrict__ state, size_t HW, size_t pix, int q) {
+    float s = state[(size_t)q * HW + pix];
+    s = s + state[(size_t)(4 + q) * HW + pix];
+    s = s + state[(size_t)(8 + q) * HW + pix];
+    s = s + state[(size_t)(12 + q) * HW + pix];
+    return s;
+}
+
+__device__ __forceinline__ float nan_to_num0(float x) {
+    if (x != x) return 0.0f;
+    if (isinf(x)) return x > 0.0f ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) k_meanbg_finalize(const float* __restrict__ state, int H, int W,
+                                                         float* __restrict__ mean_depth,
+                                                         uint8_t* __restrict__ mean_rgb) {
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+    const float cnt = (float)((const int*)state)[16 * HW + pix];
+    mean_depth[pix] = nan_to_num0(folded_sum(state, HW, pix, 0) / cnt);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float m = nan_to_num0(folded_sum(state, HW, pix, q) / cnt);
+        const float c = fminf(fmaxf(m * 255.0f, 0.0f), 255.0f);
+        mean_rgb[pix * 3 + (q - 1)] = (uint8_t)c;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_meanbg_export(const float* __restrict__ state, int H, int W,
+                                                       float* __restrict__ sums4, int32_t* __restrict__ count) {
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sums4[(size_t)q * HW + pix] = folded_sum(state, HW, pix, q);
+    count[pix] = ((const int*)state)[16 * HW + pix];
+}
+
+__global__ void __launch_bounds__(256) k_meanbg_import(float* __restrict__ state, int H, int W,
+                                                       const float* __restrict__ sums4,
+                                                       const int32_t* __restrict__ count) {
+    const size_t HW = (size_t)H * W;
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= HW) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        state[(size_t)q * HW + pix] = sums4[(size_t)q * HW + pix];
+        state[(size_t)(4 + q) * HW + pix] = 0.0f;
+        state[(size_t)(8 + q) * HW + pix] = 0.0f;
+        state[(size_t)(12 + q) * HW + pix] = 0.0f;
+    }
+    ((int*)state)[16 * HW + pix] = count[pix];
+}
+
+}  // namespace ep
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct CompactWs {
+    uint8_t* flags;
+    uint32_t* block_count;
+    uint32_t* block_offset;
+    int n_blocks;
+};
+
+size_t compact_ws_bytes(int64_t n) {
+    const int64_t nb = (n + EP_CB - 1) / EP_CB + 1;
+    return align_up((size_t)n + 16, 256) + 2 * align_up((size_t)nb * sizeof(uint32_t), 256);
+}
+
+bool carve_compact_ws(void* ws, size_t bytes, int64_t n, CompactWs& c) {
+    if (ws == nullptr || bytes < compact_ws_bytes(n)) return false;
+    const int64_t nb = (n + EP_CB - 1) / EP_CB + 1;
+    char* p = (char*)ws;
+    c.flags = (uint8_t*)p;
+    p += align_up((size_t)n + 16, 256);
+    c.block_count = (uint32_t*)p;
+    p += align_up((size_t)nb * sizeof(uint32_t), 256);
+    c.block_offset = (uint32_t*)p;
+    c.n_blocks = (int)((n + EP_CB - 1) / EP_CB);
+    return true;
+}
+
+int launch_flags(const float* d_depth, const uint8_t* d_mask, int H, int W, int s, int select, uint8_t* flags,
+                 hipStream_t st) {
+    const int Hs = (H + s - 1) / s, Ws = (W + s - 1) / s;
+    if (s <= 4) {
+        const int fw = (EP_MASK_SX - 1) * s + 5, fh = (EP_MASK_SY - 1) * s + 5;
+        const dim3 grid((Ws + EP_MASK_SX - 1) / EP_MASK_SX, (Hs + EP_MASK_SY - 1) / EP_MASK_SY);
+        hipLaunchKernelGGL(ep::k_reliable_flags, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,
+                           H, W, s, Hs, Ws, select, flags);
+    } else {
+        const int64_t n = (int64_t)Hs * Ws;
+        hipLaunchKernelGGL(ep::k_reliable_flags_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_depth,
+                           d_mask, H, W, s, Hs, Ws, select, flags);
+    }
+    return ep_host::check_launch("reliable_flags");
+}
+
+}  // namespace
+
+extern "C" int egoprior_reliable_depth_mask(const float* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out,
+                                            void* stream) {
+    if (d_depth == nullptr || d_mask_out == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad image size");
+    return launch_flags(d_depth, nullptr, H, W, 1, EGOPRIOR_SELECT_ALL, d_mask_out, (hipStream_t)stream);
+}
+
+extern "C" size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32_t subsample) {
+    if (H <= 0 || W <= 0 || subsample <= 0) return 0;
+    const int64_t Hs = (H + subsample - 1) / subsample, Ws = (W + subsample - 1) / subsample;
+    return compact_ws_bytes(Hs * Ws);
+}
+
+extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
+                                        const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
+                                        int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes,
+                                        void* stream) {
+    if (p == nullptr || d_depth == nullptr || d_rgb == nullptr || d_points == nullptr || d_count == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (p->H <= 0 || p->W <= 0 || p->subsample <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad frame geometry");
+    if (p->select < EGOPRIOR_SELECT_STATIC || p->select > EGOPRIOR_SELECT_ALL)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "unknown select rule");
+    const int s = p->subsample;
+    const int Hs = (p->H + s - 1) / s, Ws = (p->W + s - 1) / s;
+    const int64_t n = (int64_t)Hs * Ws;
+    CompactWs c;
+    if (!carve_compact_ws(d_workspace, workspace_bytes, n, c))
+        return ep_host::fail(EGOPRIOR_E_WORKSPACE, "unproject workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = launch_flags(d_depth, d_mask, p->H, p->W, s, p->select, c.flags, st)) return e;
+    hipLaunchKernelGGL(ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
+    hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
+                       d_flags);
+    hipLaunchKernelGGL(ep::k_unproject_scatter, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
+                       c.block_offset, d_points, d_xyz64, d_flags);
+    return ep_host::check_launch("unproject_frame");
+}
+
+extern "C" size_t egoprior_filter_workspace_bytes(int64_t N) { return N < 0 ? 0 : compact_ws_bytes(N > 0 ? N : 1); }
+
+extern "C" int egoprior_filter_cloud(const float* d_xyz, const uint8_t* d_rgb, int64_t N, egoprior_point* d_points,
+                                     int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (N < 0 || N > 0x7FFFFFF0ll) return ep_host::fail(EGOPRIOR_E_INVALID, "point count out of range");
+    if (d_count == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "d_count is NULL");
+    if (N > 0 && (d_xyz == nullptr || d_rgb == nullptr || d_points == nullptr))
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    CompactWs c;
+    if (!carve_compact_ws(d_workspace, workspace_bytes, N > 0 ? N : 1, c))
+        return ep_host::fail(EGOPRIOR_E_WORKSPACE, "filter workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) {
+        hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, 0, d_count,
+                           d_flags);
+        return ep_host::check_launch("filter_cloud");
+    }
+    hipLaunchKernelGGL(ep::k_filter_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_xyz, N, c.flags);
+    hipLaunchKernelGGL(ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, N, c.block_count);
+    hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
+                       d_flags);
+    hipLaunchKernelGGL(ep::k_filter_scatter, dim3(c.n_blocks), dim3(256), 0, st, d_xyz, d_rgb, N, c.flags,
+                       c.block_offset, d_points, d_flags);
+    return ep_host::check_launch("filter_cloud");
+}
+
+extern "C" size_t egoprior_meanbg_state_bytes(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    return (size_t)17 * (size_t)H * (size_t)W * sizeof(float);
+}
+
+extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, const uint8_t* d_rgb,
+                                          const uint8_t* d_mask, int32_t F, int64_t first_index, int32_t H, int32_t W,
+                                          void* stream) {
+    if (d_state == nullptr || d_depth == nullptr || d_rgb == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0 || F < 0 || first_index < 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    if (first_index + F >= (1ll << 19))
+        return ep_host::fail(EGOPRIOR_E_UNSUPPORTED, "more than 2^19 frames changes the cascade run length");
+    if (F == 0) return 0;
+    const dim3 grid((W + EP_MASK_SX - 1) / EP_MASK_SX, (H + EP_MASK_SY - 1) / EP_MASK_SY);
+    hipLaunchKernelGGL(ep::k_meanbg_accumulate, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
+                       F, (long long)first_index, H, W);
+    return ep_host::check_launch("meanbg_accumulate");
+}
+
+extern "C" int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t W, float* d_mean_depth,
+                                        uint8_t* d_mean_rgb, void* stream) {
+    if (d_state == nullptr || d_mean_depth == nullptr || d_mean_rgb == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(ep::k_meanbg_finalize, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_state, H, W, d_mean_depth, d_mean_rgb);
+    return ep_host::check_launch("meanbg_finalize");
+}
+
+extern "C" int egoprior_meanbg_export(const float* d_state, int32_t H, int32_t W, float* d_sums4, int32_t* d_count,
+                                      void* stream) {
+    if (d_state == nullptr || d_sums4 == nullptr || d_count == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(ep::k_meanbg_export, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_state, H, W, d_sums4, d_count);
+    return ep_host::check_launch("meanbg_export");
+}
+
+extern "C" int egoprior_meanbg_import(float* d_state, int32_t H, int32_t W, const float* d_sums4,
+                                      const int32_t* d_count, void* stream) {
+    if (d_state == nullptr || d_sums4 == nullptr || d_count == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(ep::k_meanbg_import, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_state, H, W, d_sums4, d_count);
+    return ep_host::check_launch("meanbg_import");
+}

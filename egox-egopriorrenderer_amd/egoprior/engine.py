@@ -1,0 +1,317 @@
+"""Device-side engine: owns HBM buffers (as torch tensors) and drives the C ABI on the current HIP stream.
+
+torch is used for device memory, streams and (elsewhere) torch.distributed only; all arithmetic of the path runs in
+the HIP kernels behind include/egoprior.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Camera, RasterParams, UnprojectParams, check
+
+F32 = np.float32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class DeviceCloud:
+    """A compacted cloud in HBM: `points` is (capacity, 4) float32 whose 4th column holds the packed colour bytes;
+    `count` (int32[1]) is the live length, `flags` (int32[1]) is 1 when some colour byte exceeds 1."""
+    points: torch.Tensor
+    count: torch.Tensor
+    flags: torch.Tensor
+    xyz64: Optional[torch.Tensor] = None
+
+    @property
+    def capacity(self) -> int:
+        return int(self.points.shape[0])
+
+    def n(self) -> int:
+        return int(self.count.item())
+
+    def to_numpy(self):
+        """(points float32 (N,3), colours uint8 (N,3)) of the live part."""
+        n = self.n()
+        p = self.points[:n].cpu().numpy()
+        rgba = p[:, 3].copy().view(np.uint32)
+        cols = np.stack([rgba & 0xFF, (rgba >> 8) & 0xFF, (rgba >> 16) & 0xFF], axis=1).astype(np.uint8)
+        return p[:, :3].copy(), cols
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# host-side camera set-up (mirrors the reference's host code; tiny, float32 numpy)
+# ----------------------------------------------------------------------------------------------------------------------
+def radius_ndc(point_size, H: int, W: int) -> float:
+    """scripts/render_vipe_pointcloud.py:853-855."""
+    r = float(point_size) * (2.0 / max(W, H))
+    return max(1e-5, min(0.25, r))
+
+
+def make_raster_params(point_size, H: int, W: int, K: int = 20, rotate_cw: bool = False,
+                       colors_gt1: int = -1) -> RasterParams:
+    r = radius_ndc(point_size, H, W)
+    return RasterParams(radius=float(F32(r)), radius_sq_w=float(F32(r * r)), K=int(K), rotate_cw=int(rotate_cw),
+                        colors_gt1=int(colors_gt1))
+
+
+def split_w2c(T_w2c):
+    T = np.asarray(T_w2c)
+    if T.shape == (4, 4):
+        return T[:3, :3], T[:3, 3]
+    if T.shape == (3, 4):
+        return T[:, :3], T[:, 3]
+    raise ValueError(f"T_w2c must be (3,4) or (4,4), got {T.shape}")
+
+
+def pinhole_camera(R_cv, t_cv, K, H: int, W: int) -> Camera:
+    """pytorch3d cameras_from_opencv_projection(R, tvec, camera_matrix, image_size=[[H, W]]) in float32
+    (scripts/render_vipe_pointcloud.py:840-850)."""
+    R = np.asarray(R_cv, dtype=F32)
+    t = np.asarray(t_cv, dtype=F32)
+    K = np.asarray(K, dtype=F32)
+    scale = F32(min(W, H)) / F32(2.0)
+    c0 = np.array([F32(W) / F32(2.0), F32(H) / F32(2.0)], dtype=F32)
+    focal = (np.array([K[0, 0], K[1, 1]], dtype=F32) / scale).astype(F32)
+    pp = (-(np.array([K[0, 2], K[1, 2]], dtype=F32) - c0) / scale).astype(F32)
+    R_p3d = R.T.copy()
+    R_p3d[:, :2] *= F32(-1)
+    T_p3d = t.copy()
+    T_p3d[:2] *= F32(-1)
+    cam = Camera()
+    cam.model, cam.H, cam.W = _lib.CAM_PINHOLE, int(H), int(W)
+    cam.R[:] = [float(v) for v in R_p3d.reshape(-1)]
+    cam.T[:] = [float(v) for v in T_p3d]
+    cam.fx, cam.fy, cam.px, cam.py = float(focal[0]), float(focal[1]), float(pp[0]), float(pp[1])
+    return cam
+
+
+def fisheye_camera(R_cv, t_cv, f_px, cx_px, cy_px, radial, tangential, thin_prism, H: int, W: int) -> Camera:
+    """The reference's FishEyeCameras set-up (scripts/render_vipe_pointcloud.py:990-1062)."""
+    R = np.asarray(R_cv, dtype=F32)
+    t = np.asarray(t_cv, dtype=F32)
+    Cm = (np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1]], dtype=F32)
+          @ np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1]], dtype=F32))
+    R_p3d = (R.T @ Cm).astype(F32)
+    T_p3d = (Cm.T @ t).astype(F32)
+    f_ndc = 2.0 * f_px / W
+    cx_ndc = 2.0 * (cx_px / W) - 1.0
+    cy_ndc = 1.0 - 2.0 * (cy_px / H)
+    cam = Camera()
+    cam.model, cam.H, cam.W = _lib.CAM_FISHEYE, int(H), int(W)
+    cam.R[:] = [float(v) for v in R_p3d.reshape(-1)]
+    cam.T[:] = [float(v) for v in T_p3d]
+    cam.fx = cam.fy = float(F32(f_ndc))
+    cam.px, cam.py = float(F32(cx_ndc)), float(F32(cy_ndc))
+    cam.radial[:] = [float(F32(v)) for v in radial]
+    cam.tangential[:] = [float(F32(v)) for v in tangential]
+    cam.thin_prism[:] = [float(F32(v)) for v in thin_prism]
+    return cam
+
+
+def make_unproject_params(H, W, subsample, select, intr, c2w, T_cam_to_world) -> UnprojectParams:
+    p = UnprojectParams()
+    p.H, p.W, p.subsample, p.select = int(H), int(W), int(subsample), int(select)
+    intr = np.asarray(intr, dtype=F32)
+    p.fx, p.fy, p.cx, p.cy = float(intr[0]), float(intr[1]), float(intr[2]), float(intr[3])
+    c = np.asarray(c2w, dtype=F32)
+    p.c2w[:] = [float(v) for v in c[:3, :4].reshape(-1)]
+    T = np.asarray(T_cam_to_world, dtype=np.float64)
+    p.T[:] = [float(v) for v in T[:3, :4].reshape(-1)]
+    return p
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# engine
+# ----------------------------------------------------------------------------------------------------------------------
+class Engine:
+    """Holds reusable workspaces on one GPU.  Not thread-safe; one per process/GPU."""
+
+    def __init__(self, device: str | torch.device = "cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("the ego-prior renderer needs a ROCm GPU (there is no CPU path)")
+        self.L = _lib.lib()
+        self._ws = {}
+
+    # -- buffers ------------------------------------------------------------------------------------------------------
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        cur = self._ws.get(key)
+        if cur is None or cur.numel() < nbytes:
+            cur = torch.empty(int(nbytes * 1.25) + 256 if cur is not None else int(nbytes), dtype=torch.uint8,
+                              device=self.device)
+            self._ws[key] = cur
+        return cur
+
+    def new_cloud(self, capacity: int, want_xyz64: bool = False) -> DeviceCloud:
+        cap = max(int(capacity), 1)
+        return DeviceCloud(
+            points=torch.empty((cap, 4), dtype=torch.float32, device=self.device),
+            count=torch.zeros(1, dtype=torch.int32, device=self.device),
+            flags=torch.zeros(1, dtype=torch.int32, device=self.device),
+            xyz64=torch.empty((cap, 3), dtype=torch.float64, device=self.device) if want_xyz64 else None)
+
+    def to_device(self, a, dtype) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+
+    # -- R5 -----------------------------------------------------------------------------------------------------------
+    def reliable_depth_mask(self, depth) -> torch.Tensor:
+        d = self.to_device(depth, torch.float32)
+        H, W = d.shape
+        out = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_reliable_depth_mask(_ptr(d), H, W, _ptr(out), _stream()))
+        return out.bool()
+
+    # -- R6 / R7 ------------------------------------------------------------------------------------------------------
+    def unproject_frame(self, depth, rgb, mask, intr, c2w, T_cam_to_world, subsample: int = 2,
+                        select: int = _lib.SELECT_STATIC, out: Optional[DeviceCloud] = None,
+                        want_xyz64: bool = False) -> DeviceCloud:
+        d = self.to_device(depth, torch.float32)
+        c = self.to_device(rgb, torch.uint8)
+        m = None if mask is None else self.to_device(mask, torch.uint8)
+        H, W = d.shape
+        if tuple(c.shape) != (H, W, 3):
+            raise ValueError(f"rgb must be ({H},{W},3), got {tuple(c.shape)}")
+        if m is not None and tuple(m.shape) != (H, W):
+            raise ValueError(f"mask must be ({H},{W}), got {tuple(m.shape)}")
+        s = int(subsample)
+        ns = ((H + s - 1) // s) * ((W + s - 1) // s)
+        if out is None:
+            out = self.new_cloud(ns, want_xyz64)
+        if out.capacity < ns or (want_xyz64 and out.xyz64 is None):
+            raise ValueError("output cloud too small")
+        p = make_unproject_params(H, W, s, select, intr, c2w, T_cam_to_world)
+        nbytes = self.L.egoprior_unproject_workspace_bytes(H, W, s)
+        ws = self._workspace("unproject", nbytes)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_unproject_frame(C.byref(p), _ptr(d), _ptr(c), _ptr(m), _ptr(out.points),
+                                                  _ptr(out.xyz64) if want_xyz64 else None, _ptr(out.count),
+                                                  _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
+        return out
+
+    # -- render-entry filters -----------------------------------------------------------------------------------------
+    def filter_cloud(self, xyz, rgb_u8) -> DeviceCloud:
+        x = self.to_device(xyz, torch.float32).reshape(-1, 3)
+        c = self.to_device(rgb_u8, torch.uint8).reshape(-1, 3)
+        if x.shape[0] != c.shape[0]:
+            raise ValueError("points and colours differ in length")
+        n = int(x.shape[0])
+        out = self.new_cloud(n)
+        nbytes = self.L.egoprior_filter_workspace_bytes(n)
+        ws = self._workspace("filter", nbytes)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_filter_cloud(_ptr(x) if n else None, _ptr(c) if n else None, n, _ptr(out.points),
+                                               _ptr(out.count), _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
+        return out
+
+    # -- R8 -----------------------------------------------------------------------------------------------------------
+    def meanbg_new_state(self, H: int, W: int) -> torch.Tensor:
+        return torch.zeros((17, H, W), dtype=torch.float32, device=self.device)
+
+    def meanbg_accumulate(self, state: torch.Tensor, depth, rgb, mask, first_index: int = 0) -> None:
+        d = self.to_device(depth, torch.float32)
+        c = self.to_device(rgb, torch.uint8)
+        m = None if mask is None else self.to_device(mask, torch.uint8)
+        if d.dim() == 2:
+            d, c = d[None], c[None]
+            m = None if m is None else m[None]
+        Fn, H, W = d.shape
+        if tuple(state.shape) != (17, H, W):
+            raise ValueError("state does not match the frame size")
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_meanbg_accumulate(_ptr(state), _ptr(d), _ptr(c), _ptr(m), Fn, int(first_index), H, W,
+                                                    _stream()))
+
+    def meanbg_finalize(self, state: torch.Tensor):
+        _, H, W = state.shape
+        md = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        mc = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_meanbg_finalize(_ptr(state), H, W, _ptr(md), _ptr(mc), _stream()))
+        return md, mc
+
+    def meanbg_export(self, state: torch.Tensor):
+        _, H, W = state.shape
+        sums = torch.empty((4, H, W), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((H, W), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_meanbg_export(_ptr(state), H, W, _ptr(sums), _ptr(cnt), _stream()))
+        return sums, cnt
+
+    def meanbg_import(self, state: torch.Tensor, sums: torch.Tensor, cnt: torch.Tensor) -> None:
+        _, H, W = state.shape
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_meanbg_import(_ptr(state), H, W, _ptr(sums.contiguous()), _ptr(cnt.contiguous()),
+                                                _stream()))
+
+    # -- R9..R12 ------------------------------------------------------------------------------------------------------
+    def project_points(self, cam: Camera, a: DeviceCloud, b: Optional[DeviceCloud] = None) -> torch.Tensor:
+        n = a.capacity + (b.capacity if b is not None else 0)
+        out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_project_points(C.byref(cam), _ptr(a.points), a.capacity, _ptr(a.count),
+                                                 _ptr(b.points) if b is not None else None,
+                                                 b.capacity if b is not None else 0,
+                                                 _ptr(b.count) if b is not None else None, _ptr(out), _stream()))
+        return out
+
+    def _alloc_outputs(self, H, W, K, rotate_cw, want_f32, want_fragments):
+        shape = (W, H, 3) if rotate_cw else (H, W, 3)
+        img = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        f32 = torch.empty((H, W, 3), dtype=torch.float32, device=self.device) if want_f32 else None
+        idx = zb = ds = None
+        if want_fragments:
+            idx = torch.empty((H, W, K), dtype=torch.int32, device=self.device)
+            zb = torch.empty((H, W, K), dtype=torch.float32, device=self.device)
+            ds = torch.empty((H, W, K), dtype=torch.float32, device=self.device)
+        return img, f32, idx, zb, ds
+
+    def rasterize_composite(self, ndc: torch.Tensor, n_live: Optional[torch.Tensor], rp: RasterParams, H: int, W: int,
+                            flags: Sequence[Optional[torch.Tensor]] = (None, None), want_f32: bool = False,
+                            want_fragments: bool = False):
+        """ndc: (n,4) float32 device tensor (x_ndc, y_ndc, z, packed colour)."""
+        n = int(ndc.shape[0])
+        img, f32, idx, zb, ds = self._alloc_outputs(H, W, rp.K, bool(rp.rotate_cw), want_f32, want_fragments)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nbytes = self.L.egoprior_raster_workspace_bytes(H, W, n, rp.radius)
+        ws = self._workspace("raster", nbytes)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_rasterize_composite(C.byref(rp), H, W, _ptr(ndc), n, _ptr(n_live), _ptr(flags[0]),
+                                                      _ptr(flags[1]), _ptr(img), _ptr(f32), _ptr(idx), _ptr(zb),
+                                                      _ptr(ds), _ptr(status), _ptr(ws), ws.numel(), _stream()))
+        return dict(image=img, image_f32=f32, idx=idx, zbuf=zb, dists=ds, status=status)
+
+    def render_frame(self, cam: Camera, rp: RasterParams, a: DeviceCloud, b: Optional[DeviceCloud] = None,
+                     want_f32: bool = False, want_fragments: bool = False, out_image: Optional[torch.Tensor] = None):
+        H, W = cam.H, cam.W
+        n = a.capacity + (b.capacity if b is not None else 0)
+        img, f32, idx, zb, ds = self._alloc_outputs(H, W, rp.K, bool(rp.rotate_cw), want_f32, want_fragments)
+        if out_image is not None:
+            if out_image.shape != img.shape or out_image.dtype != torch.uint8 or not out_image.is_contiguous():
+                raise ValueError("out_image has the wrong shape/dtype")
+            img = out_image
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nbytes = self.L.egoprior_render_workspace_bytes(H, W, n, rp.radius)
+        ws = self._workspace("render", nbytes)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_render_frame(
+                C.byref(cam), C.byref(rp), _ptr(a.points), a.capacity, _ptr(a.count), _ptr(a.flags),
+                _ptr(b.points) if b is not None else None, b.capacity if b is not None else 0,
+                _ptr(b.count) if b is not None else None, _ptr(b.flags) if b is not None else None,
+                _ptr(img), _ptr(f32), _ptr(idx), _ptr(zb), _ptr(ds), _ptr(status), _ptr(ws), ws.numel(), _stream()))
+        return dict(image=img, image_f32=f32, idx=idx, zbuf=zb, dists=ds, status=status)

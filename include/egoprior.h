@@ -1,0 +1,181 @@
+/*
+ * egoprior.h -- C ABI of the MI355X (gfx950) ego-prior renderer.
+ *
+ * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE pointers owned by the caller
+ * (inputs const, outputs and workspace pre-allocated by the caller); `stream` is a hipStream_t passed as void*.
+ * All calls are asynchronous on `stream`, allocate nothing, and return 0 on success or a negative EGOPRIOR_E_* code;
+ * egoprior_last_error() then returns a message (thread-local).  No entry point touches the host copy of any device
+ * buffer; status words that kernels produce (counts, overflow flags) live in caller-provided device memory.
+ *
+ * The reference this replaces is scripts/render_vipe_pointcloud.py of kdh8156/EgoX-EgoPriorRenderer; each entry point
+ * cites the reference lines it stands in for (paths relative to the reference checkout).  Where the reference delegates
+ * to pytorch3d v0.7.9 the pytorch3d function is named too.
+ */
+#ifndef EGOPRIOR_H_
+#define EGOPRIOR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGOPRIOR_ABI_VERSION 1
+#define EGOPRIOR_MAX_K 20 /* points_per_pixel the reference always uses (:861, :1073) */
+#define EGOPRIOR_TILE 16  /* binning tile edge in pixels */
+
+enum {
+    EGOPRIOR_OK = 0,
+    EGOPRIOR_E_INVALID = -1,   /* bad argument (null pointer, non-positive size, unknown enum) */
+    EGOPRIOR_E_WORKSPACE = -2, /* workspace too small for the request */
+    EGOPRIOR_E_HIP = -3,       /* a HIP runtime call or kernel launch failed */
+    EGOPRIOR_E_UNSUPPORTED = -4
+};
+
+/* which pixels of a frame become points (instance-mask rule) */
+enum {
+    EGOPRIOR_SELECT_STATIC = 0,  /* mask == 0  (all pixels when d_mask is NULL)  -- :409-416, :547-552 */
+    EGOPRIOR_SELECT_DYNAMIC = 1, /* mask != 0  (no pixel when d_mask is NULL)    -- :725-734 */
+    EGOPRIOR_SELECT_ALL = 2      /* ignore the mask                              -- :635 (mean cloud) */
+};
+
+enum { EGOPRIOR_CAM_PINHOLE = 0, EGOPRIOR_CAM_FISHEYE = 1 };
+
+/* One point of a device-resident cloud: world xyz (float32) + colour bytes r | g<<8 | b<<16 in `rgba`. */
+typedef struct egoprior_point {
+    float x, y, z;
+    uint32_t rgba;
+} egoprior_point;
+
+/* Exo-frame unprojection parameters (one ViPE frame). */
+typedef struct egoprior_unproject_params {
+    int32_t H, W;      /* full-resolution frame size */
+    int32_t subsample; /* spatial_subsample, >= 1 (reference default 2) */
+    int32_t select;    /* EGOPRIOR_SELECT_* */
+    float fx, fy, cx, cy; /* ViPE pinhole intrinsics of the frame */
+    float c2w[12];     /* exo camera -> ViPE world, row-major 3x4, float32 (pose npz `data`) */
+    double T[12];      /* ViPE world -> Ego4D world (= inv(exo W2C) promoted to float64), row-major 3x4 */
+} egoprior_unproject_params;
+
+/* Ego camera in pytorch3d's row-vector convention, Xv = Xw * R + T.  The host fills it exactly as the reference's
+ * host code does (cameras_from_opencv_projection for pinhole, :990-1044 for fisheye). */
+typedef struct egoprior_camera {
+    int32_t model; /* EGOPRIOR_CAM_* */
+    int32_t H, W;  /* raster size (rows, columns) */
+    float R[9];    /* row-major 3x3 */
+    float T[3];
+    float fx, fy;  /* NDC focal length (fisheye: fx == fy == f_ndc) */
+    float px, py;  /* NDC principal point */
+    float radial[6], tangential[2], thin_prism[4]; /* fisheye only */
+} egoprior_camera;
+
+typedef struct egoprior_raster_params {
+    float radius;        /* float32(radius_ndc), radius_ndc = clamp(point_size*2/max(W,H), 1e-5, 0.25)  (:853-855) */
+    float radius_sq_w;   /* float32(radius_ndc*radius_ndc) with the product taken in double: the weights' denominator */
+    int32_t K;           /* points_per_pixel, 1..EGOPRIOR_MAX_K */
+    int32_t rotate_cw;   /* 1: write the uint8 frame rotated 90 deg clockwise (W rows x H columns) (:888) */
+    int32_t colors_gt1;  /* 1: colour bytes are divided by 255 (the reference's `if cols.max() > 1` rule, :833-834);
+                            0: used as they are; -1: decide from the per-cloud flags d_flags_a/d_flags_b */
+} egoprior_raster_params;
+
+const char* egoprior_last_error(void);
+int egoprior_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * reliable_depth_mask_range(depth)  --  vipe/utils/depth.py:385-422.
+ * d_depth (H,W) float32 -> d_mask_out (H,W) uint8 (1 = reliable).
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_reliable_depth_mask(const float* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * One exo frame -> compacted points.  Stands in for the per-frame body of build_background_pointcloud (:358-430,
+ * 442-445), build_dynamic_points_for_frame (:682-751) and the unprojection half of
+ * build_mean_background_pointcloud (:594-654): rays * depth, c2w, reliability mask & instance rule on the [::s, ::s]
+ * grid, row-major compaction, exo->world in float64.
+ *   d_depth (H,W) f32, d_rgb (H,W,3) u8, d_mask (H,W) u8 or NULL.
+ *   d_points: capacity ceil(H/s)*ceil(W/s) records; d_xyz64 (optional, same capacity x 3 doubles) receives the
+ *   float64 coordinates the reference returns to Python; d_count: one int32, number of points written;
+ *   d_flags: one int32, set to 1 when any written colour byte exceeds 1 (else 0).
+ * Workspace: egoprior_unproject_workspace_bytes(H, W, subsample).
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32_t subsample);
+int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
+                             const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
+                             int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Mean background  --  compute_robust_mean_tensors (:459-473) + the frame loop of build_mean_background_pointcloud
+ * (:522-583) + colour quantisation (:638).
+ * State per pixel: 4 cascade levels x (depth, r, g, b) float32 sums + int32 count, planar, 17*H*W*4 bytes, zeroed by
+ * the caller before the first accumulate call.  Frames are d_depth (F,H,W) f32, d_rgb (F,H,W,3) u8, d_mask (F,H,W) u8
+ * or NULL; frame f of this call is term number first_index+f of the per-pixel sums (the order of summation follows
+ * torch.nanmean on CPU: runs of 16 terms, 4 levels).
+ * finalize: mean_depth (H,W) f32 with NaN->0, mean colour bytes (H,W,3) = trunc(clamp(mean*255, 0, 255)).
+ * egoprior_meanbg_export / _import move the order-insensitive form of a state (folded sums + count, 5 planes) so that
+ * ranks can all-reduce it; after an import the state holds the folded sums at level 0.
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t egoprior_meanbg_state_bytes(int32_t H, int32_t W);
+int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, const uint8_t* d_rgb, const uint8_t* d_mask,
+                               int32_t F, int64_t first_index, int32_t H, int32_t W, void* stream);
+int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t W, float* d_mean_depth, uint8_t* d_mean_rgb,
+                             void* stream);
+int egoprior_meanbg_export(const float* d_state, int32_t H, int32_t W, float* d_sums4, int32_t* d_count, void* stream);
+int egoprior_meanbg_import(float* d_state, int32_t H, int32_t W, const float* d_sums4, const int32_t* d_count,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Render-entry filters of render_points_pytorch3d / render_points_fisheye (:800-824, :953-974): float32 cast is the
+ * caller's, this drops rows with a non-finite coordinate or |p| >= 1e6 and compacts in order.
+ *   d_xyz (N,3) f32, d_rgb (N,3) u8 -> d_points (capacity N), d_count, d_flags as in egoprior_unproject_frame.
+ * Workspace: egoprior_filter_workspace_bytes(N).
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t egoprior_filter_workspace_bytes(int64_t N);
+int egoprior_filter_cloud(const float* d_xyz, const uint8_t* d_rgb, int64_t N, egoprior_point* d_points,
+                          int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * PointsRasterizer.transform (pytorch3d) as used at :863-871 / :1075-1083: world -> view -> NDC x,y with z = view
+ * depth.  Cloud = [a | b] (b may be NULL); the live length of each part is n_* unless d_n_* (device int32) is given,
+ * in which case n_* is the capacity.  d_ndc receives (x_ndc, y_ndc, z_view, rgba) per point.
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_a, int64_t n_a, const int32_t* d_n_a,
+                            const egoprior_point* d_b, int64_t n_b, const int32_t* d_n_b, egoprior_point* d_ndc,
+                            void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * pytorch3d rasterize_points(points_ndc, image_size=(H,W), radius, points_per_pixel=K) + PointsRenderer weights +
+ * AlphaCompositor(background (0,0,0)) + the reference's post-processing (:874-888, :1086-1097), on points already in
+ * NDC (d_ndc from egoprior_project_points, n = capacity, d_n = optional live count).
+ * Outputs (each optional, NULL to skip):
+ *   d_image_u8  (H,W,3) uint8, or (W,H,3) when rotate_cw      -- the frame the reference returns
+ *   d_image_f32 (H,W,3) float32                               -- compositor output before clamp / dark rule
+ *   d_idx, d_zbuf, d_dists (H,W,K) int32 / f32 / f32, -1 pad  -- rasterize_points' three outputs
+ * Workspace: egoprior_raster_workspace_bytes(H, W, n, radius); a frame whose tile lists outgrow it sets the int32 at
+ * d_status to 1 (else 0) and leaves the outputs unspecified -- call again with a workspace sized by
+ * egoprior_raster_workspace_bytes_exact after reading d_status (the default size covers every point overlapping
+ * (2*ceil(r_px/16)+1)^2 tiles, i.e. it never overflows unless n grows).
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
+int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, int32_t W, const egoprior_point* d_ndc,
+                                 int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
+                                 uint8_t* d_image_u8, float* d_image_f32, int32_t* d_idx, float* d_zbuf,
+                                 float* d_dists, int32_t* d_status, void* d_workspace, size_t workspace_bytes,
+                                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * One ego frame end to end = render_points_pytorch3d (:754-890) or render_points_fisheye (:892-1102) after their
+ * host-side filters: egoprior_project_points followed by egoprior_rasterize_composite, sharing one workspace.
+ * Workspace: egoprior_render_workspace_bytes(H, W, n_a + n_b, radius).
+ * --------------------------------------------------------------------------------------------------------------- */
+size_t egoprior_render_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
+int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_params* rp, const egoprior_point* d_a,
+                          int64_t n_a, const int32_t* d_n_a, const int32_t* d_flags_a, const egoprior_point* d_b,
+                          int64_t n_b, const int32_t* d_n_b, const int32_t* d_flags_b, uint8_t* d_image_u8,
+                          float* d_image_f32, int32_t* d_idx, float* d_zbuf, float* d_dists, int32_t* d_status,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOPRIOR_H_ */

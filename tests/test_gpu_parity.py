@@ -1,0 +1,335 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle on identical inputs.
+
+Tolerances (the bar): index maps, validity masks, point counts/order, colours and uint8 frames are compared bit-exact;
+floating-point outputs are compared bit-exact too wherever the oracle fixes the operation order (everything except the
+fisheye projection, whose atan differs between libm and the GPU math library: 1e-5 relative there).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32 = np.float32
+
+
+def pack_ndc(ndc, cols_u8, device):
+    n = ndc.shape[0]
+    rec = np.zeros((max(n, 1), 4), dtype=F32)
+    rec[:n, :3] = ndc
+    c = np.asarray(cols_u8, dtype=np.uint32).reshape(-1, 3)
+    rgba = (c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)).astype(np.uint32)
+    rec[:n, 3] = rgba.view(F32)
+    return torch.from_numpy(rec).to(device)
+
+
+def synthetic_clip(H=120, W=208, F=3):
+    from egoprior import synth
+    d, rgb, m = synth.make_frames(H, W, range(F), F)
+    E = synth.exo_w2c()
+    T = np.linalg.inv(E)
+    return dict(depth=d.numpy(), rgb=rgb.numpy(), mask=m.numpy(), intr=synth.exo_intrinsics(H, W),
+                c2w=np.eye(4, dtype=F32), T=T, E=E, egos=synth.ego_orbit_w2c(F, E))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_reliable_mask_matches_oracle_and_golden(engine):
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "g1_rays_mask.npz")
+    for key_d, key_m in (("depth", "mask"), ("depth2", "mask2")):
+        got = engine.reliable_depth_mask(g[key_d]).cpu().numpy()
+        assert np.array_equal(got, g[key_m])
+    clip = synthetic_clip(135, 241, 1)  # odd sizes: partial blocks on both axes
+    got = engine.reliable_depth_mask(clip["depth"][0]).cpu().numpy()
+    assert np.array_equal(got, O.reliable_depth_mask_range(clip["depth"][0]))
+    rng = np.random.default_rng(0)
+    d = (rng.random((77, 130), dtype=F32) * 0.1 + 2.0).astype(F32)
+    d[rng.random(d.shape) < 0.02] = np.nan
+    d[rng.random(d.shape) < 0.02] = 0.0
+    d[rng.random(d.shape) < 0.01] = np.inf
+    d[rng.random(d.shape) < 0.01] = -1.0
+    got = engine.reliable_depth_mask(d).cpu().numpy()
+    assert np.array_equal(got, O.reliable_depth_mask_range(d))
+
+
+@pytest.mark.parametrize("s", [1, 2, 3, 5])
+@pytest.mark.parametrize("select", ["static", "dynamic"])
+def test_unproject_frame(engine, s, select):
+    from egoprior import _lib
+    clip = synthetic_clip(120, 208, 2)
+    sel = _lib.SELECT_STATIC if select == "static" else _lib.SELECT_DYNAMIC
+    # a non-trivial exo pose so that the float32 c2w product is exercised
+    c2w = np.eye(4, dtype=F32)
+    a = 0.1
+    c2w[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=F32)
+    c2w[:3, 3] = [0.1, -0.2, 0.3]
+    for c in (clip["c2w"], c2w):
+        ref_p, ref_c = O.unproject_frame(clip["depth"][1], clip["rgb"][1], clip["mask"][1], clip["intr"], c, clip["T"],
+                                         s, select)
+        cloud = engine.unproject_frame(clip["depth"][1], clip["rgb"][1], clip["mask"][1], clip["intr"], c, clip["T"],
+                                       subsample=s, select=sel, want_xyz64=True)
+        n = cloud.n()
+        assert n == ref_p.shape[0]
+        p32, cols = cloud.to_numpy()
+        assert np.array_equal(cols, ref_c)
+        assert np.array_equal(cloud.xyz64[:n].cpu().numpy(), ref_p)  # float64 exo->world, bit-exact
+        assert np.array_equal(p32, ref_p.astype(F32))
+        assert cloud.flags.item() == int(ref_c.size > 0 and ref_c.max() > 1)
+
+
+def test_unproject_without_mask(engine):
+    from egoprior import _lib
+    clip = synthetic_clip(64, 96, 1)
+    ref_p, ref_c = O.unproject_frame(clip["depth"][0], clip["rgb"][0], None, clip["intr"], clip["c2w"], clip["T"], 2,
+                                     "static")
+    cloud = engine.unproject_frame(clip["depth"][0], clip["rgb"][0], None, clip["intr"], clip["c2w"], clip["T"],
+                                   subsample=2, select=_lib.SELECT_STATIC)
+    p32, cols = cloud.to_numpy()
+    assert np.array_equal(p32, ref_p.astype(F32)) and np.array_equal(cols, ref_c)
+    cloud = engine.unproject_frame(clip["depth"][0], clip["rgb"][0], None, clip["intr"], clip["c2w"], clip["T"],
+                                   subsample=2, select=_lib.SELECT_DYNAMIC)
+    assert cloud.n() == 0  # no mask file => no dynamic points (reference :728-729)
+
+
+def test_filter_cloud(engine):
+    rng = np.random.default_rng(1)
+    pts = (rng.standard_normal((5000, 3)) * 3).astype(F32)
+    pts[10] = [np.nan, 0, 0]
+    pts[11] = [0, np.inf, 0]
+    pts[12] = [2e6, 0, 0]
+    pts[13] = [6e5, 6e5, 6e5]  # norm > 1e6
+    pts[14] = [5e5, 5e5, 5e5]  # norm < 1e6
+    pts[4999] = [0, 0, -np.inf]
+    cols = rng.integers(0, 256, (5000, 3), dtype=np.uint8)
+    ref_p, ref_c = O.filter_points(pts, cols)
+    cloud = engine.filter_cloud(pts, cols)
+    p32, c8 = cloud.to_numpy()
+    assert np.array_equal(p32, ref_p)
+    assert np.array_equal(c8.astype(F32) / F32(255), ref_c)
+    assert cloud.flags.item() == 1
+    # colours that never exceed 1 are not rescaled (reference :833-834)
+    cols01 = rng.integers(0, 2, (100, 3), dtype=np.uint8)
+    cloud = engine.filter_cloud(pts[100:200], cols01)
+    assert cloud.flags.item() == 0
+    empty = engine.filter_cloud(np.zeros((0, 3), F32), np.zeros((0, 3), np.uint8))
+    assert empty.n() == 0
+
+
+def _cams(clip, He, We):
+    from egoprior import engine as eng, synth
+    K = synth.ego_pinhole_K(He, We)
+    R, t = O.split_w2c(clip["egos"][0])
+    fx = synth.load_camera_fixture()
+    prm = fx["online_calibration_line0"]["CameraCalibrations"][0]["Projection"]["Params"]
+    f, cx, cy = O.scale_intrinsics_single(prm[0], prm[1], prm[2], (2880, 2880), (He, We))
+    return K, R, t, (f, cx, cy, prm[3:9], prm[9:11], prm[11:15]), eng
+
+
+@pytest.mark.parametrize("size", [(96, 160), (128, 128), (160, 96)])
+def test_project_points(engine, size):
+    He, We = size
+    clip = synthetic_clip(120, 208, 1)
+    K, R, t, fe, eng = _cams(clip, He, We)
+    pts, cols = O.unproject_frame(clip["depth"][0], clip["rgb"][0], clip["mask"][0], clip["intr"], clip["c2w"],
+                                  clip["T"], 1, "static")
+    # points behind / on the camera plane too
+    C = -R.T @ t
+    extra = np.stack([C + R.T @ np.array([0.1, 0.1, -1.0]), C + R.T @ np.array([0.3, -0.2, 0.0])])
+    pts = np.vstack([pts, extra])
+    cols = np.vstack([cols, np.zeros((2, 3), np.uint8)])
+    cloud = engine.filter_cloud(pts.astype(F32), cols)
+    p32, _ = cloud.to_numpy()
+    ref = O.project_pinhole(p32, R, t, K, He, We)
+    got = engine.project_points(eng.pinhole_camera(R, t, K, He, We), cloud)[:cloud.n(), :3].cpu().numpy()
+    assert np.array_equal(got, ref, equal_nan=True)  # fixed operation order, no FMA: bit-exact
+    f, cx, cy, rad, tan, thin = fe
+    ref = O.project_fisheye(p32, R, t, f, cx, cy, rad, tan, thin, He, We)
+    got = engine.project_points(eng.fisheye_camera(R, t, f, cx, cy, rad, tan, thin, He, We), cloud)
+    got = got[:cloud.n(), :3].cpu().numpy()
+    ok = np.isfinite(ref).all(axis=1)
+    assert np.array_equal(np.isfinite(got).all(axis=1), ok)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-6)  # atanf: GPU math library vs libm
+    assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
+
+
+def _check_fragments(res, ref_idx, ref_z, ref_d, K):
+    assert np.array_equal(res["idx"].cpu().numpy(), ref_idx[..., :K])
+    assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z[..., :K])
+    assert np.array_equal(res["dists"].cpu().numpy(), ref_d[..., :K])
+
+
+@pytest.mark.parametrize("size,ps", [((64, 64), 1.0), ((96, 160), 3.0), ((160, 96), 5.0), ((50, 70), 8.0)])
+def test_rasterize_composite_on_identical_ndc(engine, size, ps):
+    from egoprior import engine as eng
+    He, We = size
+    clip = synthetic_clip(120, 208, 1)
+    K, R, t, _, _ = _cams(clip, He, We)
+    pts, cols = O.unproject_frame(clip["depth"][0], clip["rgb"][0], None, clip["intr"], clip["c2w"], clip["T"], 1,
+                                  "static")
+    p32, c01 = O.filter_points(pts, cols)
+    ndc = O.project_pinhole(p32, R, t, K, He, We)
+    r = O.radius_ndc(ps, He, We)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, He, We, 20, "scatter")
+    ref_img = O.composite(ref_idx, ref_d, c01, r)
+    for rot in (False, True):
+        rp = eng.make_raster_params(ps, He, We, K=20, rotate_cw=rot, colors_gt1=1)
+        res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, He, We, want_f32=True,
+                                         want_fragments=True)
+        assert res["status"].item() == 0
+        _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+        assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+        assert np.array_equal(res["image"].cpu().numpy(), O.postprocess(ref_img, rotate_cw=rot))
+    # smaller K = the first K slots
+    rp = eng.make_raster_params(ps, He, We, K=5, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, He, We, want_fragments=True)
+    _check_fragments(res, ref_idx, ref_z, ref_d, 5)
+
+
+def test_rasterize_known_answers_and_ties(engine):
+    """Hand-built cases: z ties resolved by index, a point exactly on the radius boundary, z < 0, z = 0, NaN, more than
+    K hits on one pixel, points outside the image."""
+    from egoprior import engine as eng
+    H = W = 16
+    ps = 2.0
+    r = O.radius_ndc(ps, H, W)
+    xf, yf = O.pixel_ndc_centres(H, W)
+    pts = []
+    for k in range(30):  # 30 coincident discs on pixel (5, 7) with equal z: the 20 lowest indices must win, in order
+        pts.append([xf[7], yf[5], 2.0])
+    pts.append([xf[3], yf[3], 1.0])
+    pts.append([xf[3], yf[3], 1.0])  # exact tie pair
+    pts.append([xf[10] + F32(r), yf[10], 1.5])  # centre-to-pixel distance == r: strict < fails for pixel (10,10)
+    pts.append([xf[12], yf[12], -0.5])  # behind
+    pts.append([xf[12], yf[12], 0.0])  # z == 0 is kept
+    pts.append([xf[13], yf[13], -0.0])
+    pts.append([np.nan, yf[1], 1.0])
+    pts.append([xf[1], np.inf, 1.0])
+    pts.append([5.0, 5.0, 1.0])  # far outside
+    pts.append([xf[0] + F32(0.5) * F32(r), yf[0], 3.0])  # partly outside the image
+    ndc = np.asarray(pts, dtype=F32)
+    rng = np.random.default_rng(2)
+    cols = rng.integers(0, 256, (ndc.shape[0], 3), dtype=np.uint8)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, 20, "naive")
+    assert list(ref_idx[5, 7]) == list(range(20))
+    assert list(ref_idx[3, 3][:2]) == [30, 31]
+    rp = eng.make_raster_params(ps, H, W, K=20, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, H, W, want_f32=True,
+                                     want_fragments=True)
+    _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+    ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+    assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+
+
+def test_rasterize_empty_and_all_behind(engine):
+    from egoprior import engine as eng
+    H, W = 40, 56
+    rp = eng.make_raster_params(3.0, H, W, colors_gt1=1)
+    ndc = np.array([[0.0, 0.0, -1.0], [0.1, 0.1, -2.0]], dtype=F32)
+    res = engine.rasterize_composite(pack_ndc(ndc, np.full((2, 3), 255, np.uint8), engine.device), None, rp, H, W,
+                                     want_fragments=True)
+    assert (res["idx"].cpu().numpy() == -1).all() and (res["image"].cpu().numpy() == 0).all()
+    live0 = torch.zeros(1, dtype=torch.int32, device=engine.device)
+    res = engine.rasterize_composite(pack_ndc(ndc, np.full((2, 3), 255, np.uint8), engine.device), live0, rp, H, W)
+    assert (res["image"].cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("fisheye", [False, True])
+def test_render_frame_end_to_end(engine, fisheye):
+    """static + dynamic clouds built on the GPU from a synthetic frame, rendered from an ego pose."""
+    from egoprior import _lib, engine as eng
+    He, We = (112, 112) if fisheye else (96, 160)
+    ps = 3.0
+    clip = synthetic_clip(120, 208, 2)
+    K, R, t, fe, _ = _cams(clip, He, We)
+    args = (clip["depth"][1], clip["rgb"][1], clip["mask"][1], clip["intr"], clip["c2w"], clip["T"])
+    bg = engine.unproject_frame(*args, subsample=1, select=_lib.SELECT_STATIC)
+    dyn = engine.unproject_frame(*args, subsample=1, select=_lib.SELECT_DYNAMIC)
+    rp_ = O.unproject_frame(*args, 1, "static")
+    rd_ = O.unproject_frame(*args, 1, "dynamic")
+    pts = np.vstack([rp_[0], rd_[0]])
+    cols = np.vstack([rp_[1], rd_[1]])
+    if not fisheye:
+        ref_img, fr = O.render_points_pinhole(pts, cols, K, clip["egos"][0], We, He, ps, return_fragments=True)
+        cam = eng.pinhole_camera(R, t, K, He, We)
+        rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
+        res = engine.render_frame(cam, rp, bg, dyn, want_fragments=True)
+        assert res["status"].item() == 0
+        _check_fragments(res, fr["idx"], fr["zbuf"], fr["dists"], 20)
+        assert np.array_equal(res["image"].cpu().numpy(), ref_img)
+        again = engine.render_frame(cam, rp, bg, dyn, want_fragments=True)
+        assert torch.equal(again["image"], res["image"]) and torch.equal(again["idx"], res["idx"])  # deterministic
+    else:
+        f, cx, cy, rad, tan, thin = fe
+        cam = eng.fisheye_camera(R, t, f, cx, cy, rad, tan, thin, He, We)
+        rp = eng.make_raster_params(ps, He, We, rotate_cw=False)
+        res = engine.render_frame(cam, rp, bg, dyn, want_f32=True, want_fragments=True)
+        # the GPU's own NDC coordinates -> oracle rasterizer + compositor: everything downstream is bit-exact
+        ndc = engine.project_points(cam, bg, dyn)[:bg.n() + dyn.n(), :3].cpu().numpy()
+        r = O.radius_ndc(ps, He, We)
+        ref_idx, ref_z, ref_d = O.rasterize(ndc, r, He, We, 20, "scatter")
+        _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+        ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+        assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+        assert np.array_equal(res["image"].cpu().numpy(), O.postprocess(ref_img, rotate_cw=False))
+        # and against the all-CPU frame: only pixels whose coverage flips on a 1-ulp atan difference may differ
+        full = O.render_points_fisheye(pts, cols, clip["egos"][0], f, cx, cy, rad, tan, thin, We, He, ps)
+        diff = (res["image"].cpu().numpy().astype(int) - full.astype(int))
+        assert (np.abs(diff).max(axis=2) > 1).mean() < 2e-3
+
+
+@pytest.mark.parametrize("F", [1, 5, 17, 40])
+def test_mean_background(engine, F):
+    from egoprior import _lib
+    clip = synthetic_clip(72, 128, F)  # 72*128 is a multiple of 32 (see oracle.cascade_nansum)
+    ref_d, ref_c = O.mean_background(clip["depth"], clip["rgb"], clip["mask"])
+    st = engine.meanbg_new_state(72, 128)
+    engine.meanbg_accumulate(st, clip["depth"], clip["rgb"], clip["mask"], 0)
+    md, mc = engine.meanbg_finalize(st)
+    assert np.array_equal(md.cpu().numpy(), ref_d)
+    ref_q = np.clip(ref_c * F32(255), 0, 255).astype(np.uint8)
+    assert np.array_equal(mc.cpu().numpy(), ref_q)
+    # frame-at-a-time accumulation gives the same state (term indices drive the cascade, not call boundaries)
+    st2 = engine.meanbg_new_state(72, 128)
+    for f in range(F):
+        engine.meanbg_accumulate(st2, clip["depth"][f], clip["rgb"][f], clip["mask"][f], f)
+    assert torch.equal(st2, st)
+    # mean cloud = unprojection of the mean maps with the ALL rule
+    ref_p, ref_cols = O.build_mean_background_points(clip["depth"], clip["rgb"], clip["mask"], clip["intr"],
+                                                     clip["c2w"], clip["T"], 2)
+    cloud = engine.unproject_frame(md, mc, None, clip["intr"], clip["c2w"], clip["T"], subsample=2,
+                                   select=_lib.SELECT_ALL, want_xyz64=True)
+    n = cloud.n()
+    assert n == ref_p.shape[0]
+    assert np.array_equal(cloud.xyz64[:n].cpu().numpy(), ref_p)
+    assert np.array_equal(cloud.to_numpy()[1], ref_cols)
+
+
+def test_mean_background_matches_torch_nanmean(engine):
+    """The same reduction through torch.nanmean on CPU (what the reference calls)."""
+    clip = synthetic_clip(72, 128, 19)
+    d = torch.from_numpy(clip["depth"].copy())
+    rgb = torch.from_numpy(clip["rgb"]).float() / 255.0
+    for f in range(19):
+        ok = torch.from_numpy(O.reliable_depth_mask_range(clip["depth"][f]) & (clip["mask"][f] == 0))
+        d[f][~ok] = float("nan")
+        rgb[f][~ok] = float("nan")
+    ref_d = torch.nan_to_num(torch.nanmean(d, dim=0), nan=0.0)
+    ref_c = (torch.nan_to_num(torch.nanmean(rgb, dim=0), nan=0.0) * 255).clamp(0, 255).to(torch.uint8)
+    st = engine.meanbg_new_state(72, 128)
+    engine.meanbg_accumulate(st, clip["depth"], clip["rgb"], clip["mask"], 0)
+    md, mc = engine.meanbg_finalize(st)
+    assert torch.equal(md.cpu(), ref_d)
+    assert torch.equal(mc.cpu(), ref_c)
+
+
+def test_bad_arguments_raise(engine):
+    from egoprior import _lib, engine as eng
+    rp = eng.make_raster_params(3.0, 32, 32)
+    rp.K = 21
+    ndc = torch.zeros((4, 4), device=engine.device)
+    with pytest.raises(_lib.EgoPriorError):
+        engine.rasterize_composite(ndc, None, rp, 32, 32)
+    with pytest.raises(ValueError):
+        eng.split_w2c(np.eye(3))

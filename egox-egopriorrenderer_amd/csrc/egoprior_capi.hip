@@ -10,3 +10,65 @@ char* error_buffer() {
 
 extern "C" const char* egoprior_last_error(void) { return ep_host::error_buffer(); }
 extern "C" int egoprior_abi_version(void) { return EGOPRIOR_ABI_VERSION; }
+
+// ---- per-kernel timing ------------------------------------------------------------------------------------------
+namespace ep_host {
+Prof& prof() {
+    static thread_local Prof p;
+    return p;
+}
+}  // namespace ep_host
+
+extern "C" int egoprior_profile_begin(void) {
+    ep_host::Prof& p = ep_host::prof();
+    for (auto& r : p.recs) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    p.recs.clear();
+    p.on = true;
+    return 0;
+}
+
+extern "C" int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls,
+                                    int32_t max_kernels, int32_t* n_kernels) {
+    ep_host::Prof& p = ep_host::prof();
+    p.on = false;
+    if (names == nullptr || total_ms == nullptr || calls == nullptr || n_kernels == nullptr || max_kernels <= 0)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    std::vector<const char*> uniq;
+    int rc = 0;
+    for (auto& r : p.recs) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess)
+            rc = EGOPRIOR_E_HIP;
+        int k = -1;
+        for (size_t i = 0; i < uniq.size(); ++i)
+            if (std::strcmp(uniq[i], r.name) == 0) k = (int)i;
+        if (k < 0 && (int)uniq.size() < max_kernels) {
+            uniq.push_back(r.name);
+            k = (int)uniq.size() - 1;
+            total_ms[k] = 0.0f;
+            calls[k] = 0;
+        }
+        if (k >= 0) {
+            total_ms[k] += ms;
+            calls[k] += 1;
+        }
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    p.recs.clear();
+    size_t off = 0;
+    for (size_t i = 0; i < uniq.size(); ++i) {
+        const size_t len = std::strlen(uniq[i]);
+        if (off + len + 2 > names_bytes) break;
+        std::memcpy(names + off, uniq[i], len);
+        off += len;
+        names[off++] = '\n';
+    }
+    if (names_bytes > 0) names[off < names_bytes ? off : names_bytes - 1] = '\0';
+    *n_kernels = (int32_t)uniq.size();
+    if (rc != 0) return ep_host::fail(rc, "event timing failed");
+    return 0;
+}

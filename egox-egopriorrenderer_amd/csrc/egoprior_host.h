@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "egoprior.h"
 
@@ -26,4 +27,41 @@ inline int check_launch(const char* what) {
     return EGOPRIOR_OK;
 }
 
+// ---- optional per-kernel timing (egoprior_profile_begin / _end): HIP events recorded on the launch stream ----
+struct ProfRec {
+    const char* name;
+    hipEvent_t start, stop;
+};
+struct Prof {
+    bool on = false;
+    std::vector<ProfRec> recs;
+};
+Prof& prof();  // thread-local (defined in egoprior_capi.hip)
+
+struct ScopedKernel {
+    hipStream_t s;
+    bool on;
+    ProfRec r;
+    ScopedKernel(const char* name, hipStream_t stream) : s(stream), on(prof().on && prof().recs.size() < 65536) {
+        if (on) {
+            r.name = name;
+            on = hipEventCreate(&r.start) == hipSuccess && hipEventCreate(&r.stop) == hipSuccess;
+            if (on) (void)hipEventRecord(r.start, s);
+        }
+    }
+    ~ScopedKernel() {
+        if (on) {
+            (void)hipEventRecord(r.stop, s);
+            prof().recs.push_back(r);
+        }
+    }
+};
+
 }  // namespace ep_host
+
+// launch + (when profiling is on) a HIP-event pair around this one kernel
+#define EP_LAUNCH(name, kernel, grid, block, shmem, stream, ...)               \
+    do {                                                                       \
+        ep_host::ScopedKernel _sk(name, stream);                               \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);   \
+    } while (0)

@@ -451,11 +451,11 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                            int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
                            const RasterWs& w, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
-    hipLaunchKernelGGL(ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor, n_tiles,
+    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor, n_tiles,
                        (uint32_t)w.capacity, d_status);
-    hipLaunchKernelGGL(ep::k_tile_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
+    EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
                        w.tile_cursor, w.list, (uint32_t)w.capacity);
-    hipLaunchKernelGGL(ep::k_splat, dim3(n_tiles), dim3(256), 0, s, g, *rp, d_ndc, w.tile_start, w.list,
+    EP_LAUNCH("k_splat", ep::k_splat, dim3(n_tiles), dim3(256), 0, s, g, *rp, d_ndc, w.tile_start, w.list,
                        (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
     return ep_host::check_launch("rasterize");
 }
@@ -486,7 +486,7 @@ extern "C" int egoprior_project_points(const egoprior_camera* cam, const egoprio
         return ep_host::fail(EGOPRIOR_E_INVALID, "unknown camera model");
     if (n_a + n_b == 0) return 0;
     ep::RasterGeom g = make_geom(cam->H > 0 ? cam->H : 1, cam->W > 0 ? cam->W : 1, 1e-3f);
-    hipLaunchKernelGGL(ep::k_project_count<true>, dim3(grid_for(n_a + n_b, 256)), dim3(256), 0, (hipStream_t)stream,
+    EP_LAUNCH("k_project_count", ep::k_project_count<true>, dim3(grid_for(n_a + n_b, 256)), dim3(256), 0, (hipStream_t)stream,
                        *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, (int32_t*)nullptr,
                        (uint32_t*)nullptr, 0);
     return ep_host::check_launch("project_points");
@@ -511,7 +511,7 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     egoprior_camera cam_unused = {};
-    hipLaunchKernelGGL(ep::k_project_count<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, cam_unused, g, d_ndc, n,
+    EP_LAUNCH("k_project_count", ep::k_project_count<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, cam_unused, g, d_ndc, n,
                        d_n, (const egoprior_point*)nullptr, (int64_t)0, (const int32_t*)nullptr,
                        (egoprior_point*)nullptr, w.total, w.tile_count, 1);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
@@ -546,7 +546,7 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
-    hipLaunchKernelGGL(ep::k_project_count<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, *cam, g, d_a, n_a, d_n_a,
+    EP_LAUNCH("k_project_count", ep::k_project_count<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, *cam, g, d_a, n_a, d_n_a,
                        n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);

@@ -484,11 +484,11 @@ int launch_flags(const float* d_depth, const uint8_t* d_mask, int H, int W, int 
     if (s <= 4) {
         const int fw = (EP_MASK_SX - 1) * s + 5, fh = (EP_MASK_SY - 1) * s + 5;
         const dim3 grid((Ws + EP_MASK_SX - 1) / EP_MASK_SX, (Hs + EP_MASK_SY - 1) / EP_MASK_SY);
-        hipLaunchKernelGGL(ep::k_reliable_flags, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,
+        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,
                            H, W, s, Hs, Ws, select, flags);
     } else {
         const int64_t n = (int64_t)Hs * Ws;
-        hipLaunchKernelGGL(ep::k_reliable_flags_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_depth,
+        EP_LAUNCH("k_reliable_flags_direct", ep::k_reliable_flags_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_depth,
                            d_mask, H, W, s, Hs, Ws, select, flags);
     }
     return ep_host::check_launch("reliable_flags");
@@ -526,10 +526,10 @@ extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, cons
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "unproject workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (int e = launch_flags(d_depth, d_mask, p->H, p->W, s, p->select, c.flags, st)) return e;
-    hipLaunchKernelGGL(ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
-    hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
+    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
+    EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
-    hipLaunchKernelGGL(ep::k_unproject_scatter, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
+    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
                        c.block_offset, d_points, d_xyz64, d_flags);
     return ep_host::check_launch("unproject_frame");
 }
@@ -548,15 +548,15 @@ extern "C" int egoprior_filter_cloud(const float* d_xyz, const uint8_t* d_rgb, i
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "filter workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) {
-        hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, 0, d_count,
+        EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, 0, d_count,
                            d_flags);
         return ep_host::check_launch("filter_cloud");
     }
-    hipLaunchKernelGGL(ep::k_filter_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_xyz, N, c.flags);
-    hipLaunchKernelGGL(ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, N, c.block_count);
-    hipLaunchKernelGGL(ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
+    EP_LAUNCH("k_filter_flags", ep::k_filter_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_xyz, N, c.flags);
+    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, N, c.block_count);
+    EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
-    hipLaunchKernelGGL(ep::k_filter_scatter, dim3(c.n_blocks), dim3(256), 0, st, d_xyz, d_rgb, N, c.flags,
+    EP_LAUNCH("k_filter_scatter", ep::k_filter_scatter, dim3(c.n_blocks), dim3(256), 0, st, d_xyz, d_rgb, N, c.flags,
                        c.block_offset, d_points, d_flags);
     return ep_host::check_launch("filter_cloud");
 }
@@ -576,7 +576,7 @@ extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, 
         return ep_host::fail(EGOPRIOR_E_UNSUPPORTED, "more than 2^19 frames changes the cascade run length");
     if (F == 0) return 0;
     const dim3 grid((W + EP_MASK_SX - 1) / EP_MASK_SX, (H + EP_MASK_SY - 1) / EP_MASK_SY);
-    hipLaunchKernelGGL(ep::k_meanbg_accumulate, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
+    EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
                        F, (long long)first_index, H, W);
     return ep_host::check_launch("meanbg_accumulate");
 }
@@ -587,7 +587,7 @@ extern "C" int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t
         return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(ep::k_meanbg_finalize, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    EP_LAUNCH("k_meanbg_finalize", ep::k_meanbg_finalize, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d_state, H, W, d_mean_depth, d_mean_rgb);
     return ep_host::check_launch("meanbg_finalize");
 }
@@ -598,7 +598,7 @@ extern "C" int egoprior_meanbg_export(const float* d_state, int32_t H, int32_t W
         return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(ep::k_meanbg_export, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    EP_LAUNCH("k_meanbg_export", ep::k_meanbg_export, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d_state, H, W, d_sums4, d_count);
     return ep_host::check_launch("meanbg_export");
 }
@@ -609,7 +609,7 @@ extern "C" int egoprior_meanbg_import(float* d_state, int32_t H, int32_t W, cons
         return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(ep::k_meanbg_import, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    EP_LAUNCH("k_meanbg_import", ep::k_meanbg_import, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d_state, H, W, d_sums4, d_count);
     return ep_host::check_launch("meanbg_import");
 }

@@ -68,6 +68,8 @@ SIGNATURES = {
     "egoprior_render_workspace_bytes": (_sz, [_i32, _i32, _i64, _f32]),
     "egoprior_render_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _vp, _i64, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "egoprior_profile_begin": (C.c_int, []),
+    "egoprior_profile_end": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _i32, _vp]),
 }
 
 _LIB = None
@@ -102,3 +104,22 @@ def lib():
 def check(code: int) -> None:
     if code != 0:
         raise EgoPriorError(code, lib().egoprior_last_error().decode("utf-8", "replace"))
+
+
+def profile_begin() -> None:
+    check(lib().egoprior_profile_begin())
+
+
+def profile_end() -> dict:
+    """{kernel name: (total milliseconds, launches)} since profile_begin()."""
+    names = C.create_string_buffer(4096)
+    ms = (C.c_float * 64)()
+    calls = (C.c_int32 * 64)()
+    n = C.c_int32(0)
+    check(lib().egoprior_profile_end(names, 4096, C.cast(ms, C.c_void_p), C.cast(calls, C.c_void_p), 64,
+                                     C.cast(C.byref(n), C.c_void_p)))
+    out = {}
+    for i, nm in enumerate(names.value.decode().split("\n")[:n.value]):
+        if nm:
+            out[nm] = (float(ms[i]), int(calls[i]))
+    return out

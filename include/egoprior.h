@@ -152,9 +152,8 @@ int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_
  *   d_image_f32 (H,W,3) float32                               -- compositor output before clamp / dark rule
  *   d_idx, d_zbuf, d_dists (H,W,K) int32 / f32 / f32, -1 pad  -- rasterize_points' three outputs
  * Workspace: egoprior_raster_workspace_bytes(H, W, n, radius); a frame whose tile lists outgrow it sets the int32 at
- * d_status to 1 (else 0) and leaves the outputs unspecified -- call again with a workspace sized by
- * egoprior_raster_workspace_bytes_exact after reading d_status (the default size covers every point overlapping
- * (2*ceil(r_px/16)+1)^2 tiles, i.e. it never overflows unless n grows).
+ * d_status to 1 (else 0) and drops the entries that do not fit.  The size the query returns reserves, for every point,
+ * the largest number of tiles a disc of that radius can overlap, so it cannot overflow for that n.
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
 int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, int32_t W, const egoprior_point* d_ndc,
@@ -174,6 +173,17 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
                           int64_t n_b, const int32_t* d_n_b, const int32_t* d_flags_b, uint8_t* d_image_u8,
                           float* d_image_f32, int32_t* d_idx, float* d_zbuf, float* d_dists, int32_t* d_status,
                           void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-kernel timing for benchmarks (no counterpart in the reference, which has no profiling on this path).
+ * Between _begin and _end every kernel launched by the calls above on the calling thread is bracketed by a pair of
+ * HIP events on its launch stream.  _end waits for them, sums the elapsed time per kernel name and returns, for up to
+ * max_kernels distinct kernels, newline-separated names, total milliseconds and launch counts.  _end synchronises
+ * with the device: keep it out of timed regions.
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_profile_begin(void);
+int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
+                         int32_t* n_kernels);
 
 #ifdef __cplusplus
 }

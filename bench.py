@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--subsample", type=int, default=1)
     ap.add_argument("--skip-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (egoprior_set_option)")
     return ap.parse_args()
 
 
@@ -72,6 +73,9 @@ def main():
 
     E = eng.Engine(dev)
     L = E.L
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     H, W = [int(v) for v in args.exo.split("x")]
     He, We = [int(v) for v in args.ego.split("x")]
     s = args.subsample
@@ -313,9 +317,10 @@ def cpu_baseline(E, bg, dyn, depth, rgb, mask, intr, c2w, T_c2w, s, cams, egos, 
     r = O.radius_ndc(point_size, He, We)
     y0 = He // 2
     t0 = time.perf_counter()
-    O.rasterize(ndc, r, He, We, 20, "naive", rows=(y0, y0 + 2))
-    t_probe = (time.perf_counter() - t0) / 2
-    rows = int(max(2, min(He - y0, target_s / max(t_probe, 1e-6))))
+    O.rasterize(ndc, r, He, We, 20, "naive", rows=(y0, y0 + threads))  # one row per thread
+    t_probe = (time.perf_counter() - t0) / threads
+    rows = int(max(threads, min(He - y0, target_s / max(t_probe, 1e-6))))
+    rows = max(threads, rows // threads * threads)
     t0 = time.perf_counter()
     idx, zb, ds = O.rasterize(ndc, r, He, We, 20, "naive", rows=(y0, y0 + rows))
     t_band = time.perf_counter() - t0

@@ -72,3 +72,34 @@ extern "C" int egoprior_profile_end(char* names, size_t names_bytes, float* tota
     if (rc != 0) return ep_host::fail(rc, "event timing failed");
     return 0;
 }
+
+// ---- options ------------------------------------------------------------------------------------------------------
+namespace {
+struct Opt {
+    const char* name;
+    int value;
+};
+Opt g_opts[] = {
+    {"splat_variant", 0},  // 0: sweep, 1024-record chunks; 1: register insertion only; 2: sweep, 64-record chunks;
+                           // 3: sweep, 512-record chunks
+    {"bin_lds", 1},        // 1: aggregate tile counts / slot reservations per workgroup in LDS
+};
+}  // namespace
+
+namespace ep_host {
+int option(const char* name) {
+    for (auto& o : g_opts)
+        if (std::strcmp(o.name, name) == 0) return o.value;
+    return -1;
+}
+}  // namespace ep_host
+
+extern "C" int egoprior_set_option(const char* name, int32_t value) {
+    if (name == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "option name is NULL");
+    for (auto& o : g_opts)
+        if (std::strcmp(o.name, name) == 0) {
+            o.value = value;
+            return 0;
+        }
+    return ep_host::fail(EGOPRIOR_E_INVALID, "unknown option");
+}

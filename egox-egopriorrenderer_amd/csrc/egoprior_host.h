@@ -27,6 +27,9 @@ inline int check_launch(const char* what) {
     return EGOPRIOR_OK;
 }
 
+// ---- tuning / test options (egoprior_set_option); unknown names read as -1 -----------------------------------
+int option(const char* name);
+
 // ---- optional per-kernel timing (egoprior_profile_begin / _end): HIP events recorded on the launch stream ----
 struct ProfRec {
     const char* name;

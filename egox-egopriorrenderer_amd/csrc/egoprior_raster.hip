@@ -5,8 +5,8 @@
 //                     per-tile counts                                        [HBM-bound: 16 B in, 16 B out per point]
 //   k_tile_scan     : exclusive scan of the tile counts (one workgroup)
 //   k_tile_fill     : same rectangle, wave-aggregated slot reservation, writes point indices into the tile lists
-//   k_splat         : one workgroup per 16x16 tile, one lane per pixel; streams the tile's points through LDS and
-//                     keeps each pixel's K smallest (depth-bits, index) keys, then composites front to back and
+//   k_splat_sweep   : one wave per 8x8 tile, one lane per pixel; buckets the tile's points by key in LDS, sweeps them
+//                     front to back keeping each pixel's K smallest (depth-bits, index) keys, then composites and
 //                     writes the uint8 frame (and, on request, pytorch3d's idx / zbuf / dists)
 //
 // The per-pixel key is the 64-bit value (float bits of z) << 32 | point index.  z >= 0 here, so unsigned integer
@@ -64,10 +64,13 @@ __device__ __forceinline__ void project_point(const egoprior_camera& c, float x,
 // wave-aggregated per-tile counting / slot reservation
 // ------------------------------------------------------------------------------------------------------------------
 // Every lane walks its own tile rectangle; step k of all lanes is handled together: lanes that name the same tile
-// are found with ballots and one lane issues a single atomic for the group.  FILL=false only counts.
-template <bool FILL>
+// are found with ballots and one lane issues a single atomic for the group.
+//   MODE 0: counters[t] += group size
+//   MODE 1: slot = tile_start[t] + (counters[t] += group size)   (counters = per-tile cursors in global memory)
+//   MODE 2: slot = (counters[t] += group size)                   (counters = absolute next-slot words, e.g. in LDS)
+template <int MODE>
 __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                          uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_start,
+                                          uint32_t* counters, const uint32_t* __restrict__ tile_start,
                                           uint32_t* __restrict__ list, uint32_t capacity, uint32_t point_index) {
     const int w = live ? (tx1 - tx0 + 1) : 0;
     const int ntiles = live ? w * (ty1 - ty0 + 1) : 0;
@@ -87,11 +90,11 @@ __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, 
             const int tl = __builtin_amdgcn_readlane(t, leader);
             const unsigned long long same = __ballot(active && t == tl);
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&tile_count[tl], (uint32_t)__popcll(same));
-            if (FILL) {
+            if (lane == leader) base = atomicAdd(&counters[tl], (uint32_t)__popcll(same));
+            if (MODE != 0) {
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                 if (active && t == tl) {
-                    const uint32_t slot = tile_start[tl] + base + (uint32_t)lanes_below(same);
+                    const uint32_t slot = (MODE == 1 ? tile_start[tl] : 0u) + base + (uint32_t)lanes_below(same);
                     if (slot < capacity) list[slot] = point_index;
                 }
             }
@@ -107,9 +110,13 @@ __device__ __forceinline__ int64_t live_count(const int32_t* d_n, int64_t cap) {
     return v < cap ? v : cap;
 }
 
-// world cloud [a | b] -> NDC records + tile counts.  PROJECT=false: `a` already holds NDC records (b unused) and
-// nothing is written to `out`.
-template <bool PROJECT>
+#define EP_BIN_PPB 2048  // points per workgroup in the LDS-aggregated binning kernels
+
+// world cloud [a | b] -> NDC records (+ per-tile counts when do_count).  PROJECT=false: `a` already holds NDC
+// records (b unused) and nothing is written to `out`.  LDS_AGG: the workgroup first counts into an LDS histogram of
+// all tiles and then adds the non-zero entries to global memory: consecutive points of an exo frame land on the same
+// few tiles, so this replaces thousands of same-address global atomics by a handful per workgroup.
+template <bool PROJECT, bool LDS_AGG>
 __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, RasterGeom g,
                                                        const egoprior_point* __restrict__ a, int64_t cap_a,
                                                        const int32_t* __restrict__ d_n_a,
@@ -117,36 +124,52 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                                                        const int32_t* __restrict__ d_n_b,
                                                        egoprior_point* __restrict__ out, int32_t* __restrict__ d_total,
                                                        uint32_t* __restrict__ tile_count, int do_count) {
+    extern __shared__ uint32_t hist[];
+    const int n_tiles = g.tiles_x * g.tiles_y;
     const int64_t na = live_count(d_n_a, cap_a);
     const int64_t nb = (b != nullptr) ? live_count(d_n_b, cap_b) : 0;
     const int64_t n = na + nb;
     if (blockIdx.x == 0 && threadIdx.x == 0 && d_total != nullptr) *d_total = (int32_t)n;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // whole waves stay in the loop together (the binning uses wave-wide ballots)
+    if (LDS_AGG && do_count) {
+        for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
+        __syncthreads();
+    }
+    // whole waves stay in the loops together (the binning uses wave-wide ballots)
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool live = i < n;
-        float ox = 0.f, oy = 0.f, oz = -1.f;
-        if (live) {
-            const egoprior_point p = (i < na) ? a[i] : b[i - na];
-            if (PROJECT) {
-                project_point(cam, p.x, p.y, p.z, ox, oy, oz);
-                egoprior_point q;
-                q.x = ox;
-                q.y = oy;
-                q.z = oz;
-                q.rgba = p.rgba;
-                out[i] = q;
-            } else {
-                ox = p.x;
-                oy = p.y;
-                oz = p.z;
+    for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
+        const int64_t lim = (base + EP_BIN_PPB < n_round) ? base + EP_BIN_PPB : n_round;
+        for (int64_t i = base + threadIdx.x; i < lim; i += blockDim.x) {
+            const bool live = i < n;
+            float ox = 0.f, oy = 0.f, oz = -1.f;
+            if (live) {
+                const egoprior_point p = (i < na) ? a[i] : b[i - na];
+                if (PROJECT) {
+                    project_point(cam, p.x, p.y, p.z, ox, oy, oz);
+                    egoprior_point q;
+                    q.x = ox;
+                    q.y = oy;
+                    q.z = oz;
+                    q.rgba = p.rgba;
+                    out[i] = q;
+                } else {
+                    ox = p.x;
+                    oy = p.y;
+                    oz = p.z;
+                }
+            }
+            if (do_count) {
+                int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+                const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
+                bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, LDS_AGG ? hist : tile_count, nullptr, nullptr, 0u,
+                             0u);
             }
         }
-        if (do_count) {
-            int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-            const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
-            bin_point<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count, nullptr, nullptr, 0u, 0u);
+    }
+    if (LDS_AGG && do_count) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c != 0u) atomicAdd(&tile_count[t], c);
         }
     }
 }
@@ -190,26 +213,55 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     }
 }
 
+// Second binning pass: writes point indices into the tile lists.  LDS_AGG: each workgroup takes EP_BIN_PPB
+// consecutive points, counts them per tile in LDS, reserves one contiguous range per touched tile with a single
+// global atomic, then hands out the slots of that range from LDS.
+template <bool LDS_AGG>
 __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_point* __restrict__ ndc, int64_t cap,
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
                                                    uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ list,
                                                    uint32_t capacity) {
+    extern __shared__ uint32_t hist[];
+    const int n_tiles = g.tiles_x * g.tiles_y;
     const int64_t n = live_count(d_n, cap);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool live = i < n;
-        float ox = 0.f, oy = 0.f, oz = -1.f;
-        if (live) {
-            const egoprior_point p = ndc[i];
-            ox = p.x;
-            oy = p.y;
-            oz = p.z;
+    for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
+        const int64_t lim = (base + EP_BIN_PPB < n_round) ? base + EP_BIN_PPB : n_round;
+        if (LDS_AGG) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
+            __syncthreads();
         }
-        int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-        const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
-        bin_point<true>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, (uint32_t)i);
+        for (int pass = LDS_AGG ? 0 : 1; pass < 2; ++pass) {
+            for (int64_t i = base + threadIdx.x; i < lim; i += blockDim.x) {
+                const bool live = i < n;
+                float ox = 0.f, oy = 0.f, oz = -1.f;
+                if (live) {
+                    const egoprior_point p = ndc[i];
+                    ox = p.x;
+                    oy = p.y;
+                    oz = p.z;
+                }
+                int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+                const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
+                if (!LDS_AGG)
+                    bin_point<1>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity,
+                                 (uint32_t)i);
+                else if (pass == 0)
+                    bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, nullptr, 0u, 0u);
+                else
+                    bin_point<2>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, list, capacity, (uint32_t)i);
+            }
+            if (LDS_AGG && pass == 0) {
+                __syncthreads();
+                for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+                    const uint32_t c = hist[t];
+                    if (c != 0u) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -224,86 +276,51 @@ struct SplatOut {
     float* dists;
 };
 
-#define EP_SPLAT_CHUNK 256
+typedef unsigned long long u64;
 
-// One workgroup = one 16x16 tile, 4 waves, each wave an 8x8 quadrant.  Per lane: K slots kept sorted ascending by
-// key in registers (fully unrolled compare-exchange chain).
-__global__ void __launch_bounds__(256) k_splat(RasterGeom g, egoprior_raster_params rp,
-                                               const egoprior_point* __restrict__ ndc,
-                                               const uint32_t* __restrict__ tile_start,
-                                               const uint32_t* __restrict__ list, uint32_t capacity,
-                                               const int32_t* __restrict__ d_flags_a,
-                                               const int32_t* __restrict__ d_flags_b, SplatOut out) {
-    __shared__ float4 recs[EP_SPLAT_CHUNK];
-    const int tile = blockIdx.x;
-    const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
-    const int tid = threadIdx.x;
-    const int wid = tid >> 6, lane = tid & 63;
-    const int xi = txi * EP_TILE + (wid & 1) * 8 + (lane & 7);
-    const int yi = tyi * EP_TILE + (wid >> 1) * 8 + (lane >> 3);
-    const bool inside = (xi < g.W) && (yi < g.H);
-    const float xf = pix_to_ndc(g.W - 1 - xi, g.W, g.H);
-    const float yf = pix_to_ndc(g.H - 1 - yi, g.H, g.W);
-    const float r2 = g.radius2;
+__device__ __forceinline__ u64 make_key(uint32_t zbits, uint32_t idx) { return ((u64)zbits << 32) | (u64)idx; }
 
-    uint32_t kz[EP_K];  // float bits of z
-    uint32_t ki[EP_K];  // point index
-    float kd[EP_K];     // squared NDC distance
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const u64 o = ((u64)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+        const u64 o = ((u64)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Insert (nz, ni) into the per-lane list kept sorted ascending by key in registers (compare-exchange chain).
+__device__ __forceinline__ void bubble_insert(uint32_t (&kz)[EP_K], uint32_t (&ki)[EP_K], uint32_t nz, uint32_t ni) {
 #pragma unroll
     for (int k = 0; k < EP_K; ++k) {
-        kz[k] = 0xFFFFFFFFu;
-        ki[k] = 0xFFFFFFFFu;
-        kd[k] = -1.0f;
+        const bool sw = make_key(nz, ni) < make_key(kz[k], ki[k]);
+        const uint32_t tz = kz[k], ti = ki[k];
+        kz[k] = sw ? nz : tz;
+        ki[k] = sw ? ni : ti;
+        nz = sw ? tz : nz;
+        ni = sw ? ti : ni;
     }
+}
 
-    uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-    if (end > capacity) end = capacity;
-    if (beg > end) beg = end;
-    for (uint32_t c0 = beg; c0 < end; c0 += EP_SPLAT_CHUNK) {
-        const uint32_t nrec = min((uint32_t)EP_SPLAT_CHUNK, end - c0);
-        __syncthreads();
-        if ((uint32_t)tid < nrec) {
-            const uint32_t pidx = list[c0 + tid];
-            const egoprior_point p = ndc[pidx];
-            float z = p.z;
-            if (z == 0.0f) z = 0.0f;  // -0.0 -> +0.0 so that the key order is the float order
-            recs[tid] = make_float4(p.x, p.y, z, __uint_as_float(pidx));
-        }
-        __syncthreads();
-        for (uint32_t j = 0; j < nrec; ++j) {
-            const float4 r = recs[j];
-            const float dx = r.x - xf;
-            const float dy = r.y - yf;
-            const float d2 = dx * dx + dy * dy;
-            uint32_t nz = __float_as_uint(r.z);
-            uint32_t ni = __float_as_uint(r.w);
-            const unsigned long long nkey = ((unsigned long long)nz << 32) | ni;
-            const unsigned long long last = ((unsigned long long)kz[EP_K - 1] << 32) | ki[EP_K - 1];
-            const bool take = inside && (d2 < r2) && (nkey < last);
-            if (__ballot(take) == 0ull) continue;
-            if (take) {
-                float nd = d2;
-#pragma unroll
-                for (int k = 0; k < EP_K; ++k) {
-                    const unsigned long long cur = ((unsigned long long)kz[k] << 32) | ki[k];
-                    const unsigned long long nk = ((unsigned long long)nz << 32) | ni;
-                    const bool sw = nk < cur;
-                    const uint32_t tz = kz[k], ti = ki[k];
-                    const float td = kd[k];
-                    kz[k] = sw ? nz : tz;
-                    ki[k] = sw ? ni : ti;
-                    kd[k] = sw ? nd : td;
-                    nz = sw ? tz : nz;
-                    ni = sw ? ti : ni;
-                    nd = sw ? td : nd;
-                }
-            }
-        }
-    }
-
-    if (!inside) return;
-
-    // ---- compositor (pytorch3d PointsRenderer weights + alpha_composite), then the reference's post-processing
+// Front-to-back compositing of a lane's sorted fragments + the reference's post-processing + optional fragment dump.
+// d2 is recomputed from the point's NDC x, y with the same operations as the hit test, so it is the same float.
+__device__ __forceinline__ void composite_and_store(const RasterGeom& g, const egoprior_raster_params& rp,
+                                                    const egoprior_point* __restrict__ ndc,
+                                                    const uint32_t (&kz)[EP_K], const uint32_t (&ki)[EP_K], int xi,
+                                                    int yi, float xf, float yf, const int32_t* __restrict__ d_flags_a,
+                                                    const int32_t* __restrict__ d_flags_b, const SplatOut& out) {
     int scale255 = rp.colors_gt1;
     if (scale255 < 0) {
         scale255 = 0;
@@ -311,26 +328,38 @@ __global__ void __launch_bounds__(256) k_splat(RasterGeom g, egoprior_raster_par
         if (d_flags_b != nullptr && *d_flags_b != 0) scale255 = 1;
     }
     const int K = rp.K;
+    const size_t pix = (size_t)yi * (size_t)g.W + (size_t)xi;
     float cum = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
 #pragma unroll
     for (int k = 0; k < EP_K; ++k) {
-        if (k < K && ki[k] != 0xFFFFFFFFu) {
-            const uint32_t rgba = ndc[ki[k]].rgba;
-            float fr = (float)(rgba & 0xFFu), fg = (float)((rgba >> 8) & 0xFFu), fb = (float)((rgba >> 16) & 0xFFu);
+        const bool filled = (k < K) && (ki[k] != 0xFFFFFFFFu);
+        float d2 = -1.0f;
+        if (filled) {
+            const egoprior_point p = ndc[ki[k]];
+            const float dx = p.x - xf;
+            const float dy = p.y - yf;
+            d2 = dx * dx + dy * dy;
+            float fr = (float)(p.rgba & 0xFFu), fg = (float)((p.rgba >> 8) & 0xFFu),
+                  fb = (float)((p.rgba >> 16) & 0xFFu);
             if (scale255) {
                 fr = fr / 255.0f;
                 fg = fg / 255.0f;
                 fb = fb / 255.0f;
             }
-            const float alpha = 1.0f - kd[k] / rp.radius_sq_w;
+            const float alpha = 1.0f - d2 / rp.radius_sq_w;
             const float wgt = cum * alpha;
             cr += wgt * fr;
             cg += wgt * fg;
             cb += wgt * fb;
             cum = cum * (1.0f - alpha);
         }
+        if (out.idx != nullptr && k < K) {
+            const size_t o = pix * (size_t)K + (size_t)k;
+            out.idx[o] = filled ? (int32_t)ki[k] : -1;
+            if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[k]) : -1.0f;
+            if (out.dists != nullptr) out.dists[o] = d2;
+        }
     }
-    const size_t pix = (size_t)yi * (size_t)g.W + (size_t)xi;
     if (out.image_f32 != nullptr) {
         out.image_f32[pix * 3 + 0] = cr;
         out.image_f32[pix * 3 + 1] = cg;
@@ -348,18 +377,298 @@ __global__ void __launch_bounds__(256) k_splat(RasterGeom g, egoprior_raster_par
         out.image_u8[o * 3 + 1] = (uint8_t)(gg * 255.0f);
         out.image_u8[o * 3 + 2] = (uint8_t)(b * 255.0f);
     }
-    if (out.idx != nullptr) {
+}
+
+// Straightforward variant: one wave per 8x8 tile, every record of the tile list is offered to every pixel and
+// inserted into the register-resident sorted list.  Kept as the simple cross-check of k_splat_sweep (option
+// "splat_variant" = 1) and as its A/B partner in benchmarks.
+__global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_raster_params rp,
+                                                     const egoprior_point* __restrict__ ndc,
+                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint32_t* __restrict__ list, uint32_t capacity,
+                                                     const int32_t* __restrict__ d_flags_a,
+                                                     const int32_t* __restrict__ d_flags_b, SplatOut out) {
+    __shared__ float4 recs[64];
+    const int tile = blockIdx.x;
+    const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
+    const int lane = threadIdx.x;
+    const int xi = txi * EP_TILE + (lane & 7);
+    const int yi = tyi * EP_TILE + (lane >> 3);
+    const bool inside = (xi < g.W) && (yi < g.H);
+    const float xf = pix_to_ndc(g.W - 1 - xi, g.W, g.H);
+    const float yf = pix_to_ndc(g.H - 1 - yi, g.H, g.W);
+    const float r2 = g.radius2;
+    uint32_t kz[EP_K], ki[EP_K];
 #pragma unroll
-        for (int k = 0; k < EP_K; ++k) {
-            if (k < K) {
-                const bool filled = ki[k] != 0xFFFFFFFFu;
-                const size_t o = pix * (size_t)K + (size_t)k;
-                out.idx[o] = filled ? (int32_t)ki[k] : -1;
-                if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[k]) : -1.0f;
-                if (out.dists != nullptr) out.dists[o] = filled ? kd[k] : -1.0f;
-            }
+    for (int k = 0; k < EP_K; ++k) {
+        kz[k] = 0xFFFFFFFFu;
+        ki[k] = 0xFFFFFFFFu;
+    }
+    uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+    if (end > capacity) end = capacity;
+    if (beg > end) beg = end;
+    for (uint32_t c0 = beg; c0 < end; c0 += 64) {
+        const uint32_t nrec = min(64u, end - c0);
+        __syncthreads();
+        if ((uint32_t)lane < nrec) {
+            const uint32_t pidx = list[c0 + lane];
+            const egoprior_point p = ndc[pidx];
+            float z = p.z;
+            if (z == 0.0f) z = 0.0f;  // -0.0 -> +0.0 so that the key order is the float order
+            recs[lane] = make_float4(p.x, p.y, z, __uint_as_float(pidx));
+        }
+        __syncthreads();
+        for (uint32_t j = 0; j < nrec; ++j) {
+            const float4 r = recs[j];
+            const float dx = r.x - xf;
+            const float dy = r.y - yf;
+            const float d2 = dx * dx + dy * dy;
+            const uint32_t nz = __float_as_uint(r.z), ni = __float_as_uint(r.w);
+            const bool take = inside && (d2 < r2) && (make_key(nz, ni) < make_key(kz[EP_K - 1], ki[EP_K - 1]));
+            if (__ballot(take) == 0ull) continue;
+            if (take) bubble_insert(kz, ki, nz, ni);
         }
     }
+    if (!inside) return;
+    composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+}
+
+// Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
+// entries (C/64 per lane, held in registers while the chunk is organised):
+//   load    : C/64 independent index loads and record gathers per lane; records whose key cannot beat the current
+//             K-th key of any pixel of the tile are dropped
+//   sort    : monotone radix bucketing on (key - min) >> shift into LDS (histogram, scan, scatter: O(n)), then every
+//             lane insertion-sorts the short run of records that fell into its own NB/64 buckets; if some run is
+//             long (many equal depths) the whole chunk is bitonic-sorted instead.  Either way S[] ends up sorted.
+//   sweep   : the sorted records are offered front to back, 64 at a time, to all 64 pixels in a branch-free loop
+//             (record coordinates come from v_readlane, i.e. scalar operands) that builds each pixel's 64-bit hit
+//             mask; every lane then appends its hits to its slot list.  Sorted input makes the first K hits of a
+//             pixel its K nearest, so the sweep stops as soon as every pixel holds K.
+//   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
+//             later chunks: compare-exchange insertion).
+// LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
+template <int C, int NB>
+__global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
+                                                    const egoprior_point* __restrict__ ndc,
+                                                    const uint32_t* __restrict__ tile_start,
+                                                    const uint32_t* __restrict__ list, uint32_t capacity,
+                                                    const int32_t* __restrict__ d_flags_a,
+                                                    const int32_t* __restrict__ d_flags_b, SplatOut out) {
+    static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 32768 && (C & (C - 1)) == 0 && (NB & (NB - 1)) == 0, "geometry");
+    constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
+    constexpr int PER = NB / 64;  // buckets per lane
+    __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
+    __shared__ uint32_t bkt[NB];
+    __shared__ uint16_t slots[EP_K][64];
+
+    const int tile = blockIdx.x;
+    const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
+    const int lane = threadIdx.x;
+    const int xi = txi * EP_TILE + (lane & 7);
+    const int yi = tyi * EP_TILE + (lane >> 3);
+    const bool inside = (xi < g.W) && (yi < g.H);
+    const float xf = pix_to_ndc(g.W - 1 - xi, g.W, g.H);
+    const float yf = pix_to_ndc(g.H - 1 - yi, g.H, g.W);
+    const float r2 = g.radius2;
+    const int K = rp.K;
+
+    uint32_t kz[EP_K], ki[EP_K];
+#pragma unroll
+    for (int k = 0; k < EP_K; ++k) {
+        kz[k] = 0xFFFFFFFFu;
+        ki[k] = 0xFFFFFFFFu;
+    }
+    u64 T = ~0ull;  // only keys below T can still enter some pixel's top K
+    uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
+    if (end > capacity) end = capacity;
+    if (pos > end) pos = end;
+    int chunk_no = 0;
+
+    while (pos < end) {
+        // ---- load + threshold filter -----------------------------------------------------------------------------
+        uint32_t pidx[RPL];
+        bool val[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            const uint32_t e = pos + (uint32_t)(u * 64 + lane);
+            val[u] = e < end;
+            pidx[u] = val[u] ? list[e] : 0u;
+        }
+        uint4 rec[RPL];
+        u64 kmin = ~0ull, kmax = 0ull;
+        int m = 0;
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            rec[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (val[u]) {
+                const egoprior_point p = ndc[pidx[u]];
+                float z = p.z;
+                if (z == 0.0f) z = 0.0f;  // -0.0 -> +0.0: key order == float order
+                rec[u] = make_uint4(pidx[u], __float_as_uint(z), __float_as_uint(p.x), __float_as_uint(p.y));
+                const u64 key = make_key(rec[u].y, rec[u].x);
+                val[u] = key < T;
+                if (val[u]) {
+                    kmin = key < kmin ? key : kmin;
+                    kmax = key > kmax ? key : kmax;
+                }
+            }
+            m += __popcll(__ballot(val[u]));
+        }
+        pos += C;
+        if (m == 0) continue;
+        kmin = wave_min_u64(kmin);
+        kmax = wave_max_u64(kmax);
+        const u64 range = kmax - kmin;
+        int shift = 0;
+        if (range >= (u64)NB) shift = (64 - __builtin_clzll(range)) - (31 - __builtin_clz((unsigned)NB));
+        // (range >> shift) < NB: range has 64-clz significant bits and NB = 2^b keeps the top b of them
+
+        // ---- bucket: histogram, exclusive scan, scatter into S -----------------------------------------------------
+        __syncthreads();  // previous chunk's readers of S / bkt / slots are done
+#pragma unroll
+        for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPL; ++u)
+            if (val[u]) atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> shift)], 1u);
+        __syncthreads();
+        {
+            uint32_t loc[PER];
+            uint32_t sum = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                loc[q] = bkt[lane * PER + q];
+                sum += loc[q];
+            }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                bkt[lane * PER + q] = run;
+                run += loc[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RPL; ++u)
+            if (val[u]) {
+                const uint32_t p = atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> shift)], 1u);
+                S[p] = rec[u];
+            }
+        __syncthreads();
+        // bkt[b] is now the end of bucket b.  This lane's buckets cover S[seg_a, seg_b).
+        const int seg_a = (lane == 0) ? 0 : (int)bkt[lane * PER - 1];
+        const int seg_b = (int)bkt[lane * PER + PER - 1];
+        if (__ballot(seg_b - seg_a > 48) == 0ull) {
+            // records are in bucket order; only records of one bucket can be out of order: short insertion sort
+            for (int i = seg_a + 1; i < seg_b; ++i) {
+                const uint4 cur = S[i];
+                const u64 key = make_key(cur.y, cur.x);
+                int j = i - 1;
+                while (j >= seg_a) {
+                    const uint4 o = S[j];
+                    if (make_key(o.y, o.x) < key) break;
+                    S[j + 1] = o;
+                    --j;
+                }
+                if (j + 1 != i) S[j + 1] = cur;
+            }
+        } else {
+            // degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk
+            for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
+            __syncthreads();
+            for (int k2 = 2; k2 <= C; k2 <<= 1) {
+                for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                    for (int t = lane; t < C / 2; t += 64) {
+                        const int lo = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
+                        const int hi = lo | j2;
+                        const bool up = (lo & k2) == 0;
+                        const uint4 ra = S[lo], rb = S[hi];
+                        const bool gt = make_key(ra.y, ra.x) > make_key(rb.y, rb.x);
+                        if (gt == up) {
+                            S[lo] = rb;
+                            S[hi] = ra;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- sweep front to back ---------------------------------------------------------------------------------
+        int cnt = inside ? 0 : K;  // pixels outside the image never take part
+        for (int j0 = 0; j0 < m; j0 += 64) {
+            if (__ballot(cnt < K) == 0ull) break;  // every pixel already holds its K nearest of this chunk
+            const int jj = j0 + lane;
+            uint4 sr = make_uint4(0u, 0u, 0x7FC00000u, 0x7FC00000u);  // NaN coordinates never hit
+            if (jj < m) sr = S[jj];
+            uint32_t hm_lo = 0u, hm_hi = 0u;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const float rx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sr.z, t));
+                const float ry = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sr.w, t));
+                const float dx = rx - xf;
+                const float dy = ry - yf;
+                const float d2 = dx * dx + dy * dy;
+                if (t < 32)
+                    hm_lo |= (d2 < r2) ? (1u << t) : 0u;
+                else
+                    hm_hi |= (d2 < r2) ? (1u << (t - 32)) : 0u;
+            }
+            u64 hm = (cnt < K) ? (((u64)hm_hi << 32) | (u64)hm_lo) : 0ull;
+            while (__ballot(hm != 0ull) != 0ull) {
+                if (hm != 0ull) {
+                    const int t = __builtin_ctzll(hm);
+                    hm &= hm - 1ull;
+                    slots[cnt][lane] = (uint16_t)(j0 + t);
+                    ++cnt;
+                    if (cnt >= K) hm = 0ull;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- merge the chunk's winners into the running list -------------------------------------------------------
+        const int won = inside ? cnt : 0;
+        if (chunk_no == 0) {
+#pragma unroll
+            for (int k = 0; k < EP_K; ++k) {
+                if (k < won) {
+                    const uint4 w = S[slots[k][lane]];
+                    kz[k] = w.y;
+                    ki[k] = w.x;
+                }
+            }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const bool v = k < won;
+                if (__ballot(v) == 0ull) break;
+                if (v) {
+                    const uint4 w = S[slots[k][lane]];
+                    bubble_insert(kz, ki, w.y, w.x);
+                }
+            }
+        }
+        ++chunk_no;
+        if (pos < end) {
+            u64 mine = 0ull;  // outside pixels never raise the threshold
+            if (inside) {
+                mine = ~0ull;
+#pragma unroll
+                for (int k = 0; k < EP_K; ++k)
+                    if (k == K - 1) mine = make_key(kz[k], ki[k]);
+            }
+            T = wave_max_u64(mine);
+        }
+    }
+    if (!inside) return;
+    composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
 }
 
 }  // namespace ep
@@ -429,6 +738,16 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
     return true;
 }
 
+// LDS-aggregated binning needs one 32-bit counter per tile in LDS
+bool lds_agg_ok(int n_tiles) { return (size_t)n_tiles * sizeof(uint32_t) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
+
+int bin_grid(int64_t n) {
+    int64_t b = (n + EP_BIN_PPB - 1) / EP_BIN_PPB;
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (int)b;
+}
+
 int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
@@ -453,10 +772,29 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor, n_tiles,
                        (uint32_t)w.capacity, d_status);
-    EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
-                       w.tile_cursor, w.list, (uint32_t)w.capacity);
-    EP_LAUNCH("k_splat", ep::k_splat, dim3(n_tiles), dim3(256), 0, s, g, *rp, d_ndc, w.tile_start, w.list,
-                       (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+    if (lds_agg_ok(n_tiles))
+        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), sizeof(uint32_t) * n_tiles, s, g,
+                  d_ndc, n, d_n, w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
+    else
+        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<false>, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n,
+                  w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
+    switch (ep_host::option("splat_variant")) {
+        case 1:
+            EP_LAUNCH("k_splat_bubble", ep::k_splat_bubble, dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc, w.tile_start,
+                      w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 2:  // tiny chunks: forces the multi-chunk path on small inputs (tests)
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<64, 64>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 3:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 256>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        default:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 512>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+    }
     return ep_host::check_launch("rasterize");
 }
 
@@ -486,9 +824,9 @@ extern "C" int egoprior_project_points(const egoprior_camera* cam, const egoprio
         return ep_host::fail(EGOPRIOR_E_INVALID, "unknown camera model");
     if (n_a + n_b == 0) return 0;
     ep::RasterGeom g = make_geom(cam->H > 0 ? cam->H : 1, cam->W > 0 ? cam->W : 1, 1e-3f);
-    EP_LAUNCH("k_project_count", ep::k_project_count<true>, dim3(grid_for(n_a + n_b, 256)), dim3(256), 0, (hipStream_t)stream,
-                       *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, (int32_t*)nullptr,
-                       (uint32_t*)nullptr, 0);
+    EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n_a + n_b)), dim3(256), 0,
+              (hipStream_t)stream, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
+              (int32_t*)nullptr, (uint32_t*)nullptr, 0);
     return ep_host::check_launch("project_points");
 }
 
@@ -511,9 +849,14 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     egoprior_camera cam_unused = {};
-    EP_LAUNCH("k_project_count", ep::k_project_count<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, cam_unused, g, d_ndc, n,
-                       d_n, (const egoprior_point*)nullptr, (int64_t)0, (const int32_t*)nullptr,
-                       (egoprior_point*)nullptr, w.total, w.tile_count, 1);
+    if (lds_agg_ok(n_tiles))
+        EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256),
+                  sizeof(uint32_t) * n_tiles, s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
+                  (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1);
+    else
+        EP_LAUNCH("k_project_count", (ep::k_project_count<false, false>), dim3(bin_grid(n)), dim3(256), 0, s,
+                  cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr, (int64_t)0, (const int32_t*)nullptr,
+                  (egoprior_point*)nullptr, w.total, w.tile_count, 1);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, d_n, d_flags_a, d_flags_b, w, out, d_status, s);
 }
@@ -546,8 +889,13 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
-    EP_LAUNCH("k_project_count", ep::k_project_count<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, *cam, g, d_a, n_a, d_n_a,
-                       n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1);
+    if (lds_agg_ok(n_tiles))
+        EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256),
+                  sizeof(uint32_t) * n_tiles, s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
+                  w.total, w.tile_count, 1);
+    else
+        EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n)), dim3(256), 0, s, *cam, g,
+                  d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);
 }

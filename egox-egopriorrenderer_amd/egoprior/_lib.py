@@ -13,7 +13,7 @@ CSRC = _PKG.parent / "csrc"
 LIB_PATH = CSRC / "libegoprior_hip.so"
 
 MAX_K = 20
-TILE = 16
+TILE = 8
 
 E_OK, E_INVALID, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
 SELECT_STATIC, SELECT_DYNAMIC, SELECT_ALL = 0, 1, 2
@@ -68,6 +68,7 @@ SIGNATURES = {
     "egoprior_render_workspace_bytes": (_sz, [_i32, _i32, _i64, _f32]),
     "egoprior_render_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _vp, _i64, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "egoprior_set_option": (C.c_int, [C.c_char_p, _i32]),
     "egoprior_profile_begin": (C.c_int, []),
     "egoprior_profile_end": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _i32, _vp]),
 }
@@ -123,3 +124,7 @@ def profile_end() -> dict:
         if nm:
             out[nm] = (float(ms[i]), int(calls[i]))
     return out
+
+
+def set_option(name: str, value: int) -> None:
+    check(lib().egoprior_set_option(name.encode(), int(value)))

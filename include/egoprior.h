@@ -23,7 +23,7 @@ extern "C" {
 
 #define EGOPRIOR_ABI_VERSION 1
 #define EGOPRIOR_MAX_K 20 /* points_per_pixel the reference always uses (:861, :1073) */
-#define EGOPRIOR_TILE 16  /* binning tile edge in pixels */
+#define EGOPRIOR_TILE 8   /* binning tile edge in pixels: one 64-lane wave owns one 8x8 tile */
 
 enum {
     EGOPRIOR_OK = 0,
@@ -182,6 +182,10 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
  * with the device: keep it out of timed regions.
  * --------------------------------------------------------------------------------------------------------------- */
 int egoprior_profile_begin(void);
+/* Process-wide tuning / test switches (no counterpart in the reference): "splat_variant" (0 default sweep kernel,
+ * 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks to force its multi-chunk path on small
+ * inputs, 3 sweep kernel with 512-record chunks), "bin_lds" (1 default: per-workgroup LDS aggregation in binning). */
+int egoprior_set_option(const char* name, int32_t value);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
                          int32_t* n_kernels);
 

@@ -154,14 +154,33 @@ def test_project_points(engine, size):
     assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["sweep1024", "bubble", "sweep64", "sweep512"])
+def splat_variant(request):
+    """Every splat kernel variant must give the same bits: the default sweep kernel, the plain register-insertion
+    kernel, and the sweep kernel with 64- and 512-record chunks (64 forces its multi-chunk merge on these small inputs)."""
+    from egoprior import _lib
+    _lib.set_option("splat_variant", request.param)
+    yield request.param
+    _lib.set_option("splat_variant", 0)
+
+
+@pytest.fixture(params=[1, 0], ids=["binlds", "binglobal"])
+def bin_variant(request):
+    from egoprior import _lib
+    _lib.set_option("bin_lds", request.param)
+    yield request.param
+    _lib.set_option("bin_lds", 1)
+
+
 def _check_fragments(res, ref_idx, ref_z, ref_d, K):
     assert np.array_equal(res["idx"].cpu().numpy(), ref_idx[..., :K])
     assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z[..., :K])
     assert np.array_equal(res["dists"].cpu().numpy(), ref_d[..., :K])
 
 
-@pytest.mark.parametrize("size,ps", [((64, 64), 1.0), ((96, 160), 3.0), ((160, 96), 5.0), ((50, 70), 8.0)])
-def test_rasterize_composite_on_identical_ndc(engine, size, ps):
+@pytest.mark.parametrize("size,ps", [((64, 64), 1.0), ((96, 160), 3.0), ((160, 96), 5.0), ((50, 70), 8.0),
+                                     ((40, 40), 30.0)])
+def test_rasterize_composite_on_identical_ndc(engine, size, ps, splat_variant, bin_variant):
     from egoprior import engine as eng
     He, We = size
     clip = synthetic_clip(120, 208, 1)
@@ -187,7 +206,7 @@ def test_rasterize_composite_on_identical_ndc(engine, size, ps):
     _check_fragments(res, ref_idx, ref_z, ref_d, 5)
 
 
-def test_rasterize_known_answers_and_ties(engine):
+def test_rasterize_known_answers_and_ties(engine, splat_variant):
     """Hand-built cases: z ties resolved by index, a point exactly on the radius boundary, z < 0, z = 0, NaN, more than
     K hits on one pixel, points outside the image."""
     from egoprior import engine as eng
@@ -236,7 +255,7 @@ def test_rasterize_empty_and_all_behind(engine):
 
 
 @pytest.mark.parametrize("fisheye", [False, True])
-def test_render_frame_end_to_end(engine, fisheye):
+def test_render_frame_end_to_end(engine, fisheye, splat_variant):
     """static + dynamic clouds built on the GPU from a synthetic frame, rendered from an ego pose."""
     from egoprior import _lib, engine as eng
     He, We = (112, 112) if fisheye else (96, 160)

@@ -71,7 +71,7 @@ __device__ __forceinline__ void project_point(const egoprior_camera& c, float x,
 template <int MODE>
 __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                           uint32_t* counters, const uint32_t* __restrict__ tile_start,
-                                          uint32_t* __restrict__ list, uint32_t capacity, uint32_t point_index) {
+                                          uint4* __restrict__ list, uint32_t capacity, uint4 entry) {
     const int w = live ? (tx1 - tx0 + 1) : 0;
     const int ntiles = live ? w * (ty1 - ty0 + 1) : 0;
     const int lane = lane_id();
@@ -95,10 +95,30 @@ __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, 
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                 if (active && t == tl) {
                     const uint32_t slot = (MODE == 1 ? tile_start[tl] : 0u) + base + (uint32_t)lanes_below(same);
-                    if (slot < capacity) list[slot] = point_index;
+                    if (slot < capacity) list[slot] = entry;
                 }
             }
             todo &= ~same;
+        }
+    }
+}
+
+// LDS flavour of the same walk: LDS atomics resolve same-address lanes in hardware, so every lane simply bumps the
+// counter of each tile of its rectangle.  FILL: counters hold absolute next-slot numbers and the entry is written.
+template <bool FILL>
+__device__ __forceinline__ void bin_point_lds(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                              uint32_t* hist, uint4* __restrict__ list, uint32_t capacity,
+                                              uint4 entry) {
+    if (!live) return;
+    for (int ty = ty0; ty <= ty1; ++ty) {
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int t = ty * tiles_x + tx;
+            if (FILL) {
+                const uint32_t slot = atomicAdd(&hist[t], 1u);
+                if (slot < capacity) list[slot] = entry;
+            } else {
+                atomicAdd(&hist[t], 1u);
+            }
         }
     }
 }
@@ -160,8 +180,12 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
             if (do_count) {
                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
                 const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
-                bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, LDS_AGG ? hist : tile_count, nullptr, nullptr, 0u,
-                             0u);
+                if (LDS_AGG)
+                    bin_point_lds<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, 0u,
+                                         make_uint4(0u, 0u, 0u, 0u));
+                else
+                    bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count, nullptr, nullptr, 0u,
+                                 make_uint4(0u, 0u, 0u, 0u));
             }
         }
     }
@@ -174,16 +198,21 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
     }
 }
 
-// exclusive scan of tile counts; also zeroes the cursors the fill pass bumps and reports list overflow
+// exclusive scan of tile counts; also zeroes the cursors the fill pass bumps, reports list overflow, and writes the
+// launch order of the splat kernel: tiles by decreasing list length (in steps of 16 entries), so that the long tiles
+// start first and the short ones fill the tail of the launch
 __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start,
-                                                    uint32_t* __restrict__ tile_cursor, int n_tiles, uint32_t capacity,
+                                                    uint32_t* __restrict__ tile_cursor,
+                                                    uint32_t* __restrict__ tile_order, int n_tiles, uint32_t capacity,
                                                     int32_t* __restrict__ d_status) {
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
+    __shared__ uint32_t ohist[256];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
+    if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
     for (int base = 0; base < n_tiles; base += 1024) {
         const int t = base + tid;
@@ -202,6 +231,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
         if (t < n_tiles) {
             tile_start[t] = carry + woff + incl - v;
             tile_cursor[t] = 0u;
+            atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u);
         }
         __syncthreads();
         if (tid == 1023) carry_s = carry + woff + incl;
@@ -210,6 +240,17 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     if (tid == 0) {
         tile_start[n_tiles] = carry_s;
         if (d_status != nullptr) *d_status = (carry_s > capacity) ? 1 : 0;
+        uint32_t run = 0;
+        for (int b = 0; b < 256; ++b) {
+            const uint32_t c = ohist[b];
+            ohist[b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) {
+        const uint32_t v = tile_count[t];
+        tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
     }
 }
 
@@ -220,7 +261,7 @@ template <bool LDS_AGG>
 __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_point* __restrict__ ndc, int64_t cap,
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
-                                                   uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ list,
+                                                   uint32_t* __restrict__ tile_cursor, uint4* __restrict__ list,
                                                    uint32_t capacity) {
     extern __shared__ uint32_t hist[];
     const int n_tiles = g.tiles_x * g.tiles_y;
@@ -245,13 +286,15 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
                 }
                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
                 const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
+                // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order), NDC x, y
+                const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
+                                               __float_as_uint(ox), __float_as_uint(oy));
                 if (!LDS_AGG)
-                    bin_point<1>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity,
-                                 (uint32_t)i);
+                    bin_point<1>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
                 else if (pass == 0)
-                    bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, nullptr, 0u, 0u);
+                    bin_point_lds<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, 0u, entry);
                 else
-                    bin_point<2>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, list, capacity, (uint32_t)i);
+                    bin_point_lds<true>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, list, capacity, entry);
             }
             if (LDS_AGG && pass == 0) {
                 __syncthreads();
@@ -277,6 +320,23 @@ struct SplatOut {
 };
 
 typedef unsigned long long u64;
+
+// Diagnostic build only (-DEP_STAMPS): per-phase cycle totals of k_splat_sweep, summed over waves.
+#ifdef EP_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define EP_STAMP_DECL unsigned long long _t0 = clock64(), _t1
+#define EP_STAMP(slot)                                                                    \
+    do {                                                                                  \
+        _t1 = clock64();                                                                  \
+        if (threadIdx.x == 0) atomicAdd(&g_stamps[slot], (unsigned long long)(_t1 - _t0)); \
+        _t0 = _t1;                                                                        \
+    } while (0)
+#else
+#define EP_STAMP_DECL
+#define EP_STAMP(slot)
+#endif
+
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u64 make_key(uint32_t zbits, uint32_t idx) { return ((u64)zbits << 32) | (u64)idx; }
 
@@ -330,34 +390,57 @@ __device__ __forceinline__ void composite_and_store(const RasterGeom& g, const e
     const int K = rp.K;
     const size_t pix = (size_t)yi * (size_t)g.W + (size_t)xi;
     float cum = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    constexpr int G = 5;  // fragments per gather group
+    static_assert(EP_K % G == 0, "group size");
 #pragma unroll
-    for (int k = 0; k < EP_K; ++k) {
-        const bool filled = (k < K) && (ki[k] != 0xFFFFFFFFu);
-        float d2 = -1.0f;
-        if (filled) {
-            const egoprior_point p = ndc[ki[k]];
-            const float dx = p.x - xf;
-            const float dy = p.y - yf;
-            d2 = dx * dx + dy * dy;
-            float fr = (float)(p.rgba & 0xFFu), fg = (float)((p.rgba >> 8) & 0xFFu),
-                  fb = (float)((p.rgba >> 16) & 0xFFu);
-            if (scale255) {
-                fr = fr / 255.0f;
-                fg = fg / 255.0f;
-                fb = fb / 255.0f;
+    for (int h = 0; h < EP_K; h += G) {
+        // lists are filled front to back: when no pixel of the wave has a fragment at slot h, none has one beyond
+        // (wave-uniform test: whole groups of gathers are skipped for sparsely covered tiles)
+        if (__ballot(h < K && ki[h] != 0xFFFFFFFFu) != 0ull) {
+            egoprior_point p[G];  // all gathers of the group are issued before any of them is used
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
+                p[k] = ndc[filled ? ki[h + k] : 0u];  // unconditional so that the gathers overlap
             }
-            const float alpha = 1.0f - d2 / rp.radius_sq_w;
-            const float wgt = cum * alpha;
-            cr += wgt * fr;
-            cg += wgt * fg;
-            cb += wgt * fb;
-            cum = cum * (1.0f - alpha);
-        }
-        if (out.idx != nullptr && k < K) {
-            const size_t o = pix * (size_t)K + (size_t)k;
-            out.idx[o] = filled ? (int32_t)ki[k] : -1;
-            if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[k]) : -1.0f;
-            if (out.dists != nullptr) out.dists[o] = d2;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
+                float d2 = -1.0f;
+                if (filled) {
+                    const float dx = p[k].x - xf;
+                    const float dy = p[k].y - yf;
+                    d2 = dx * dx + dy * dy;
+                    float fr = (float)(p[k].rgba & 0xFFu), fg = (float)((p[k].rgba >> 8) & 0xFFu),
+                          fb = (float)((p[k].rgba >> 16) & 0xFFu);
+                    if (scale255) {
+                        fr = fr / 255.0f;
+                        fg = fg / 255.0f;
+                        fb = fb / 255.0f;
+                    }
+                    const float alpha = 1.0f - d2 / rp.radius_sq_w;
+                    const float wgt = cum * alpha;
+                    cr += wgt * fr;
+                    cg += wgt * fg;
+                    cb += wgt * fb;
+                    cum = cum * (1.0f - alpha);
+                }
+                if (out.idx != nullptr && h + k < K) {
+                    const size_t o = pix * (size_t)K + (size_t)(h + k);
+                    out.idx[o] = filled ? (int32_t)ki[h + k] : -1;
+                    if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[h + k]) : -1.0f;
+                    if (out.dists != nullptr) out.dists[o] = d2;
+                }
+            }
+        } else if (out.idx != nullptr) {
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+                if (h + k < K) {
+                    const size_t o = pix * (size_t)K + (size_t)(h + k);
+                    out.idx[o] = -1;
+                    if (out.zbuf != nullptr) out.zbuf[o] = -1.0f;
+                    if (out.dists != nullptr) out.dists[o] = -1.0f;
+                }
         }
     }
     if (out.image_f32 != nullptr) {
@@ -385,11 +468,12 @@ __device__ __forceinline__ void composite_and_store(const RasterGeom& g, const e
 __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_raster_params rp,
                                                      const egoprior_point* __restrict__ ndc,
                                                      const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ list, uint32_t capacity,
+                                                     const uint32_t* __restrict__ tile_order,
+                                                     const uint4* __restrict__ list, uint32_t capacity,
                                                      const int32_t* __restrict__ d_flags_a,
                                                      const int32_t* __restrict__ d_flags_b, SplatOut out) {
     __shared__ float4 recs[64];
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int lane = threadIdx.x;
     const int xi = txi * EP_TILE + (lane & 7);
@@ -411,11 +495,9 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
         const uint32_t nrec = min(64u, end - c0);
         __syncthreads();
         if ((uint32_t)lane < nrec) {
-            const uint32_t pidx = list[c0 + lane];
-            const egoprior_point p = ndc[pidx];
-            float z = p.z;
-            if (z == 0.0f) z = 0.0f;  // -0.0 -> +0.0 so that the key order is the float order
-            recs[lane] = make_float4(p.x, p.y, z, __uint_as_float(pidx));
+            const uint4 e = list[c0 + lane];
+            recs[lane] = make_float4(__uint_as_float(e.z), __uint_as_float(e.w), __uint_as_float(e.y),
+                                     __uint_as_float(e.x));
         }
         __syncthreads();
         for (uint32_t j = 0; j < nrec; ++j) {
@@ -435,8 +517,8 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 
 // Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
 // entries (C/64 per lane, held in registers while the chunk is organised):
-//   load    : C/64 independent index loads and record gathers per lane; records whose key cannot beat the current
-//             K-th key of any pixel of the tile are dropped
+//   load    : C/64 independent, fully coalesced 16-byte record loads per lane (the tile lists hold index, depth
+//             bits and NDC x, y); records whose key cannot beat the current K-th key of any pixel are dropped
 //   sort    : monotone radix bucketing on (key - min) >> shift into LDS (histogram, scan, scatter: O(n)), then every
 //             lane insertion-sorts the short run of records that fell into its own NB/64 buckets; if some run is
 //             long (many equal depths) the whole chunk is bitonic-sorted instead.  Either way S[] ends up sorted.
@@ -447,11 +529,12 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 //   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
 //             later chunks: compare-exchange insertion).
 // LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
-template <int C, int NB>
-__global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
+template <int C, int NB, int WPE>
+__global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
-                                                    const uint32_t* __restrict__ list, uint32_t capacity,
+                                                    const uint32_t* __restrict__ tile_order,
+                                                    const uint4* __restrict__ list, uint32_t capacity,
                                                     const int32_t* __restrict__ d_flags_a,
                                                     const int32_t* __restrict__ d_flags_b, SplatOut out) {
     static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 32768 && (C & (C - 1)) == 0 && (NB & (NB - 1)) == 0, "geometry");
@@ -461,7 +544,7 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
     __shared__ uint32_t bkt[NB];
     __shared__ uint16_t slots[EP_K][64];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)tile_order[blockIdx.x];
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int lane = threadIdx.x;
     const int xi = txi * EP_TILE + (lane & 7);
@@ -471,6 +554,9 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
     const float yf = pix_to_ndc(g.H - 1 - yi, g.H, g.W);
     const float r2 = g.radius2;
     const int K = rp.K;
+    float2v pxy;
+    pxy.x = xf;
+    pxy.y = yf;
 
     uint32_t kz[EP_K], ki[EP_K];
 #pragma unroll
@@ -483,39 +569,34 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
     if (end > capacity) end = capacity;
     if (pos > end) pos = end;
     int chunk_no = 0;
+    EP_STAMP_DECL;
 
     while (pos < end) {
+        EP_STAMP(0);
         // ---- load + threshold filter -----------------------------------------------------------------------------
-        uint32_t pidx[RPL];
+        uint4 rec[RPL];
         bool val[RPL];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
             const uint32_t e = pos + (uint32_t)(u * 64 + lane);
             val[u] = e < end;
-            pidx[u] = val[u] ? list[e] : 0u;
+            rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
         }
-        uint4 rec[RPL];
         u64 kmin = ~0ull, kmax = 0ull;
         int m = 0;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            rec[u] = make_uint4(0u, 0u, 0u, 0u);
+            const u64 key = make_key(rec[u].y, rec[u].x);
+            val[u] = val[u] && (key < T);
             if (val[u]) {
-                const egoprior_point p = ndc[pidx[u]];
-                float z = p.z;
-                if (z == 0.0f) z = 0.0f;  // -0.0 -> +0.0: key order == float order
-                rec[u] = make_uint4(pidx[u], __float_as_uint(z), __float_as_uint(p.x), __float_as_uint(p.y));
-                const u64 key = make_key(rec[u].y, rec[u].x);
-                val[u] = key < T;
-                if (val[u]) {
-                    kmin = key < kmin ? key : kmin;
-                    kmax = key > kmax ? key : kmax;
-                }
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
             }
             m += __popcll(__ballot(val[u]));
         }
         pos += C;
         if (m == 0) continue;
+        EP_STAMP(1);
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
         const u64 range = kmax - kmin;
@@ -561,6 +642,10 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
                 S[p] = rec[u];
             }
         __syncthreads();
+        // the sweep reads whole blocks of 64: pad the last block with records that never hit and sort last
+        for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
+            S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
+        EP_STAMP(2);
         // bkt[b] is now the end of bucket b.  This lane's buckets cover S[seg_a, seg_b).
         const int seg_a = (lane == 0) ? 0 : (int)bkt[lane * PER - 1];
         const int seg_b = (int)bkt[lane * PER + PER - 1];
@@ -601,38 +686,107 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
         }
         __syncthreads();
 
+        EP_STAMP(3);
         // ---- sweep front to back ---------------------------------------------------------------------------------
         int cnt = inside ? 0 : K;  // pixels outside the image never take part
-        for (int j0 = 0; j0 < m; j0 += 64) {
-            if (__ballot(cnt < K) == 0ull) break;  // every pixel already holds its K nearest of this chunk
-            const int jj = j0 + lane;
-            uint4 sr = make_uint4(0u, 0u, 0x7FC00000u, 0x7FC00000u);  // NaN coordinates never hit
-            if (jj < m) sr = S[jj];
-            uint32_t hm_lo = 0u, hm_hi = 0u;
+        // Later chunks: a pixel whose running list is full only cares about records with a key below its K-th key,
+        // and S is sorted, so those are a prefix S[0, jlim) found by binary search.
+        int jlim = m;
+        if (chunk_no > 0) {
+            u64 mine = ~0ull;
 #pragma unroll
-            for (int t = 0; t < 64; ++t) {
-                const float rx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sr.z, t));
-                const float ry = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)sr.w, t));
-                const float dx = rx - xf;
-                const float dy = ry - yf;
-                const float d2 = dx * dx + dy * dy;
-                if (t < 32)
-                    hm_lo |= (d2 < r2) ? (1u << t) : 0u;
-                else
-                    hm_hi |= (d2 < r2) ? (1u << (t - 32)) : 0u;
-            }
-            u64 hm = (cnt < K) ? (((u64)hm_hi << 32) | (u64)hm_lo) : 0ull;
-            while (__ballot(hm != 0ull) != 0ull) {
-                if (hm != 0ull) {
-                    const int t = __builtin_ctzll(hm);
-                    hm &= hm - 1ull;
-                    slots[cnt][lane] = (uint16_t)(j0 + t);
-                    ++cnt;
-                    if (cnt >= K) hm = 0ull;
+            for (int k = 0; k < EP_K; ++k)
+                if (k == K - 1) mine = make_key(kz[k], ki[k]);
+            int lo = 0, hi = m;  // first position whose key is >= mine
+            while (__ballot(lo < hi) != 0ull) {
+                if (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint4 r = S[mid];
+                    if (make_key(r.y, r.x) < mine)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
                 }
             }
+            jlim = inside ? lo : 0;
+        }
+        int m_sweep = jlim;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
+        for (int j0 = 0; j0 < m_sweep; j0 += 64) {
+#ifdef EP_STAMPS
+            if (threadIdx.x == 0) atomicAdd(&g_stamps[10], 1ull);
+#endif
+            if (__ballot(cnt < K) == 0ull) break;  // every pixel already holds its K nearest of this chunk
+            // Offer records j0 .. j0+63 to every pixel: each record's (x, y) is read from LDS at a wave-uniform
+            // address (a broadcast), subtracted and squared as a float pair, and the hit bit is shifted into the
+            // pixel's mask.  Slots past m hold NaN coordinates (written by the sort stage), which never hit.
+            uint32_t hm_lo = 0u, hm_hi = 0u;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {  // 16 records per group: all LDS reads first, then the arithmetic
+                float2v rxy[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) rxy[t] = *reinterpret_cast<const float2v*>(&S[j0 + g4 * 16 + t].z);
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float2v dxy = rxy[t] - pxy;
+                    const float2v q = dxy * dxy;
+                    const float d2 = q.x + q.y;
+                    bits |= (d2 < r2) ? (1u << t) : 0u;
+                }
+                if (g4 < 2)
+                    hm_lo |= bits << (16 * g4);
+                else
+                    hm_hi |= bits << (16 * (g4 - 2));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (cnt >= K || j0 >= jlim) {
+                hm_lo = 0u;
+                hm_hi = 0u;
+            } else if (jlim - j0 < 64) {  // this lane's prefix ends inside the block
+                const int nb = jlim - j0;
+                if (nb <= 32) {
+                    hm_hi = 0u;
+                    hm_lo &= (nb == 32) ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+                } else {
+                    hm_hi &= (1u << (nb - 32)) - 1u;
+                }
+            }
+            EP_STAMP(4);
+            // every lane appends its own hits, lowest record first
+            while (__ballot(hm_lo != 0u) != 0ull) {
+                if (hm_lo != 0u) {
+                    const int t = __builtin_ctz(hm_lo);
+                    hm_lo &= hm_lo - 1u;
+                    slots[cnt][lane] = (uint16_t)(j0 + t);
+                    ++cnt;
+                    if (cnt >= K) {
+                        hm_lo = 0u;
+                        hm_hi = 0u;
+                    }
+                }
+            }
+            while (__ballot(hm_hi != 0u) != 0ull) {
+                if (hm_hi != 0u) {
+                    const int t = __builtin_ctz(hm_hi);
+                    hm_hi &= hm_hi - 1u;
+                    slots[cnt][lane] = (uint16_t)(j0 + 32 + t);
+                    ++cnt;
+                    if (cnt >= K) hm_hi = 0u;
+                }
+            }
+            EP_STAMP(5);
         }
         __syncthreads();
+        EP_STAMP(6);
+#ifdef EP_STAMPS
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_stamps[11], (unsigned long long)((m + 63) / 64));
+            atomicAdd(&g_stamps[12], 1ull);
+        }
+#endif
 
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
         const int won = inside ? cnt : 0;
@@ -666,9 +820,11 @@ __global__ void __launch_bounds__(64) k_splat_sweep(RasterGeom g, egoprior_raste
             }
             T = wave_max_u64(mine);
         }
+        EP_STAMP(7);
     }
-    if (!inside) return;
-    composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+    EP_STAMP(8);
+    if (inside) composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+    EP_STAMP(9);
 }
 
 }  // namespace ep
@@ -712,15 +868,16 @@ struct RasterWs {
     uint32_t* tile_count;   // n_tiles
     uint32_t* tile_start;   // n_tiles + 1
     uint32_t* tile_cursor;  // n_tiles
+    uint32_t* tile_order;   // n_tiles
     int32_t* total;         // 1 (+ padding)
-    uint32_t* list;         // capacity
+    uint4* list;            // capacity records (point index, depth bits, NDC x, NDC y)
     uint64_t capacity;
     size_t header_bytes;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t raster_header_bytes(int n_tiles) { return align_up(sizeof(uint32_t) * (3 * (size_t)n_tiles + 1 + 16), 256); }
+size_t raster_header_bytes(int n_tiles) { return align_up(sizeof(uint32_t) * (4 * (size_t)n_tiles + 1 + 16), 256); }
 
 bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
     const size_t hb = raster_header_bytes(n_tiles);
@@ -729,9 +886,10 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
     r.tile_count = base;
     r.tile_start = base + n_tiles;
     r.tile_cursor = base + 2 * (size_t)n_tiles + 1;
-    r.total = (int32_t*)(base + 3 * (size_t)n_tiles + 1);
-    r.list = (uint32_t*)((char*)ws + hb);
-    uint64_t cap = (bytes - hb) / sizeof(uint32_t);
+    r.tile_order = base + 3 * (size_t)n_tiles + 1;
+    r.total = (int32_t*)(base + 4 * (size_t)n_tiles + 1);
+    r.list = (uint4*)((char*)ws + hb);
+    uint64_t cap = (bytes - hb) / sizeof(uint4);
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     r.capacity = cap;
     r.header_bytes = hb;
@@ -765,36 +923,71 @@ int check_raster_args(const egoprior_raster_params* rp, int H, int W, int64_t n)
     return 0;
 }
 
+__global__ void k_fill_f32(float* __restrict__ p, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// nothing to draw: the frame is the background and every fragment slot is empty
+int clear_outputs(int H, int W, int K, const ep::SplatOut& out, int32_t* d_status, hipStream_t s) {
+    const size_t npix = (size_t)H * (size_t)W;
+    bool ok = true;
+    if (out.image_u8 != nullptr) ok = ok && hipMemsetAsync(out.image_u8, 0, npix * 3, s) == hipSuccess;
+    if (out.image_f32 != nullptr) ok = ok && hipMemsetAsync(out.image_f32, 0, npix * 3 * sizeof(float), s) == hipSuccess;
+    if (out.idx != nullptr) ok = ok && hipMemsetAsync(out.idx, 0xFF, npix * K * sizeof(int32_t), s) == hipSuccess;
+    if (d_status != nullptr) ok = ok && hipMemsetAsync(d_status, 0, sizeof(int32_t), s) == hipSuccess;
+    if (!ok) return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
+    const size_t nk = npix * (size_t)K;
+    if (out.zbuf != nullptr)
+        EP_LAUNCH("k_fill_f32", k_fill_f32, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, out.zbuf, nk, -1.0f);
+    if (out.dists != nullptr)
+        EP_LAUNCH("k_fill_f32", k_fill_f32, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, out.dists, nk, -1.0f);
+    return ep_host::check_launch("clear_outputs");
+}
+
 // count (optionally with projection) must already have run into w.tile_count
 int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params* rp, const egoprior_point* d_ndc,
                            int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
                            const RasterWs& w, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
-    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor, n_tiles,
-                       (uint32_t)w.capacity, d_status);
+    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
+              w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
     if (lds_agg_ok(n_tiles))
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), sizeof(uint32_t) * n_tiles, s, g,
                   d_ndc, n, d_n, w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
     else
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill<false>, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n,
                   w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
+#define EP_SWEEP(C_, NB_, WPE_)                                                                                \
+    EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
+              w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
     switch (ep_host::option("splat_variant")) {
         case 1:
             EP_LAUNCH("k_splat_bubble", ep::k_splat_bubble, dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc, w.tile_start,
-                      w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+                      w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 2:  // tiny chunks: forces the multi-chunk path on small inputs (tests)
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<64, 64>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            EP_SWEEP(64, 64, 2);
             break;
         case 3:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 256>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            EP_SWEEP(512, 256, 3);
+            break;
+        case 4:
+            EP_SWEEP(512, 512, 3);
+            break;
+        case 5:
+            EP_SWEEP(256, 256, 4);
+            break;
+        case 6:
+            EP_SWEEP(1024, 1024, 2);
+            break;
+        case 7:
+            EP_SWEEP(1024, 512, 2);
             break;
         default:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 512>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            EP_SWEEP(1024, 1024, 2);
     }
+#undef EP_SWEEP
     return ep_host::check_launch("rasterize");
 }
 
@@ -805,7 +998,7 @@ extern "C" size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t 
     const ep::RasterGeom g = make_geom(H, W, radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     const uint64_t cap = (uint64_t)(n > 0 ? n : 1) * (uint64_t)tiles_per_point_bound(g);
-    return raster_header_bytes(n_tiles) + align_up((size_t)cap * sizeof(uint32_t), 256) + 256;
+    return raster_header_bytes(n_tiles) + align_up((size_t)cap * sizeof(uint4), 256) + 256;
 }
 
 extern "C" size_t egoprior_render_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius) {
@@ -841,6 +1034,7 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if ((d_zbuf != nullptr || d_dists != nullptr) && d_idx == nullptr)
         return ep_host::fail(EGOPRIOR_E_INVALID, "zbuf/dists need idx");
     hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     RasterWs w;
@@ -878,6 +1072,7 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
         return ep_host::fail(EGOPRIOR_E_INVALID, "zbuf/dists need idx");
     hipStream_t s = (hipStream_t)stream;
     const int H = cam->H, W = cam->W;
+    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     const size_t ndc_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(egoprior_point), 256);
@@ -899,3 +1094,15 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);
 }
+
+#ifdef EP_STAMPS
+extern "C" int egoprior_debug_stamps(unsigned long long* host16, int reset) {
+    if (host16 != nullptr && hipMemcpyFromSymbol(host16, HIP_SYMBOL(ep::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return -3;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stamps), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,159 @@
+"""Frame-sharded rendering over the GPUs of one node: one process per GPU (torchrun), torch.distributed with the
+"nccl" backend (RCCL over xGMI on ROCm).  The reference has no counterpart: its renderer is one process on one GPU.
+
+What is exchanged:
+  * --use_mean_bg: every rank accumulates the per-pixel sums (depth, r, g, b) and counts of ITS frames, then ONE
+    all-reduce(sum) of the 4 float32 planes and one of the int32 count plane make every rank hold the same totals;
+    every rank then finalises the identical static cloud.  (Partial sums are folded per rank, so the float32 depth/colour
+    means can differ from a single-GPU run in the last bit; the exact integer counts cannot.)
+  * accumulated background (default mode): every rank unprojects its frames' static points; the per-rank clouds are
+    all-gathered in rank (= frame) order, so point indices match the single-GPU cloud.
+  * finished uint8 frames are gathered on rank 0, which writes the video.
+Frames are split into contiguous blocks: rank r renders frames [r*F/G, (r+1)*F/G).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from pathlib import Path
+from typing import List, Sequence
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous block of rank `rank` when n_items are split as evenly as possible in order."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def allreduce_mean_state(dist, sums, counts):
+    """In-place all-reduce(sum) of the folded mean-background sums (4,H,W) float32 and counts (H,W) int32."""
+    dist.all_reduce(sums)
+    dist.all_reduce(counts)
+    return sums, counts
+
+
+def gather_frames(dist, local_frames, n_total: int, rank: int, world: int, device):
+    """Rank 0 receives every rank's (n_r, H, W, 3) uint8 block in rank order; returns the (n_total, H, W, 3) tensor on
+    rank 0 and None elsewhere.  Blocks may differ in length by one frame: they are padded to the longest."""
+    import torch
+    n_max = max(len(shard_range(n_total, r, world)) for r in range(world))
+    shape = tuple(local_frames.shape[1:])
+    pad = torch.zeros((n_max,) + shape, dtype=torch.uint8, device=device)
+    pad[:local_frames.shape[0]] = local_frames
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([bufs[r][:len(shard_range(n_total, r, world))] for r in range(world)], dim=0)
+
+
+def allgather_clouds(dist, points, count: int, world: int, device):
+    """All ranks receive the concatenation, in rank order, of every rank's first `count` rows of `points` (n,4)."""
+    import torch
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([count], dtype=torch.int64, device=device))
+    counts = [int(c.item()) for c in counts]
+    n_max = max(max(counts), 1)
+    pad = torch.zeros((n_max, points.shape[1]), dtype=points.dtype, device=device)
+    pad[:count] = points[:count]
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0), counts
+
+
+def main_distributed(argv=None):
+    """The CLI under torchrun: same flags and output as the single-GPU main()."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+    from . import engine as eng
+    from . import render_vipe_pointcloud as rv
+    from .io import ArtifactPath, write_video
+
+    logging.basicConfig(level=logging.INFO)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="nccl", device_id=device)
+    args = rv.get_parser().parse_args(argv)
+    args.out_dir = rv.configure_output_directory(args)
+    if rank == 0:
+        os.makedirs(args.out_dir, exist_ok=True)
+    _, exo_extrinsic, ego_K, ego_list = rv.load_camera_params_from_meta(args.meta_json_path, args.input_dir)
+    T = np.linalg.inv(exo_extrinsic)
+    rv.validate_frame_range(args, len(ego_list), args.input_dir)
+    E = eng.Engine(device)
+    rv._ENGINE = E
+    artifact = rv._first_artifact(args.input_dir)
+    frames = list(rv._frames(artifact, tolerant=True))  # (c2w, rgb, intr, type, depth, mask) per frame
+    n_frames = len(frames)
+    mine = shard_range(n_frames, rank, world)
+    s = 2
+    # ---- static cloud ---------------------------------------------------------------------------------------------
+    first = frames[0]
+    H, W = first[1].shape[:2]
+    if args.use_mean_bg:
+        state = E.meanbg_new_state(H, W)
+        k = 0
+        for f in mine:
+            c2w, rgb, intr, ct, depth, mask = frames[f]
+            if depth is None:
+                continue
+            E.meanbg_accumulate(state, depth, rgb, mask, k)
+            k += 1
+        sums, cnt = E.meanbg_export(state)
+        allreduce_mean_state(dist, sums, cnt)
+        E.meanbg_import(state, sums, cnt)
+        md, mc = E.meanbg_finalize(state)
+        bg = E.unproject_frame(md, mc, None, first[2], first[0], T, subsample=s, select=_lib.SELECT_ALL)
+    else:
+        parts = []
+        for f in mine:
+            c2w, rgb, intr, ct, depth, mask = frames[f]
+            if depth is None:
+                continue
+            c = E.unproject_frame(depth, rgb, mask, intr, c2w, T, subsample=s, select=_lib.SELECT_STATIC)
+            parts.append(c.points[:c.n()].clone())
+        local = torch.cat(parts, dim=0) if parts else torch.zeros((0, 4), device=device)
+        allpts, _ = allgather_clouds(dist, local, local.shape[0], world, device)
+        bg = E.new_cloud(allpts.shape[0])
+        bg.points[:allpts.shape[0]] = allpts
+        bg.count.fill_(allpts.shape[0])
+        bg.flags.fill_(1)
+    # ---- my frames ------------------------------------------------------------------------------------------------
+    to_render = list(range(args.start_frame, args.end_frame + 1))
+    my_slots = shard_range(len(to_render), rank, world)
+    size = (448, 448)
+    rad = tan = thin = foc = pp = None
+    if args.fish_eye_rendering:
+        rad, tan, thin, foc, pp = rv.load_aria_distortion_coeffs(args.online_calibration_path, frame_idx=0)
+    out = []
+    for slot in my_slots:
+        dyn = None
+        if not args.only_bg and slot < n_frames:
+            c2w, rgb, intr, ct, depth, mask = frames[slot]
+            if depth is not None and mask is not None:
+                dyn = E.unproject_frame(depth, rgb, mask, intr, c2w, T, subsample=s, select=_lib.SELECT_DYNAMIC)
+        Tw = ego_list[to_render[slot]]
+        if args.fish_eye_rendering:
+            img = rv.render_points_fisheye(None, None, Tw, ego_K, W=size[1], H=size[0], point_size=args.point_size,
+                                           radial_distortion_coeffs=rad, tangential_distortion_coeffs=tan,
+                                           thinPrism_distortion_coeffs=thin, focal_length=foc, principal_point=pp,
+                                           original_image_size=(2880, 2880), _cloud=bg, _dyn=dyn)
+        else:
+            img = rv.render_points_pytorch3d(None, None, K=ego_K, T_w2c=Tw, W=size[1], H=size[0],
+                                             point_size=args.point_size, _cloud=bg, _dyn=dyn)
+        out.append(torch.from_numpy(img).to(device))
+    local = torch.stack(out) if out else torch.zeros((0, size[0], size[1], 3), dtype=torch.uint8, device=device)
+    allf = gather_frames(dist, local, len(to_render), rank, world, device)
+    if rank == 0:
+        write_video(Path(args.out_dir) / "ego_Prior.mp4", list(allf.cpu().numpy()), fps=30)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -166,7 +166,10 @@ class Engine:
     def to_device(self, a, dtype) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype).contiguous()
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
+        return torch.from_numpy(a).to(device=self.device, dtype=dtype).contiguous()
 
     # -- R5 -----------------------------------------------------------------------------------------------------------
     def reliable_depth_mask(self, depth) -> torch.Tensor:

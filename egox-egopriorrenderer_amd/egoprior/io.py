@@ -1,0 +1,297 @@
+"""ViPE artifact layout and readers for the ego-prior renderer.
+
+Mirrors the parts of the reference's vipe/utils/io.py that the render path touches (ArtifactPath :41-146,
+read_pose_artifacts :169-171, read_intrinsics_artifacts :221-234, read_rgb_artifacts :244-251, read_depth_artifacts
+:282-312, read_instance_artifacts :315-327) with two differences that matter on a machine without imageio / OpenEXR /
+OpenCV:
+
+  * every artifact also has an array twin that needs no codec: rgb/<name>.npy (F,H,W,3) uint8, depth/<name>.npy (F,H,W)
+    float16 or float32, mask/<name>.npy (F,H,W) uint8.  The twin is used when the codec file is absent; synthetic
+    sequences are written this way (write_synthetic_artifacts).
+  * instance-mask PNGs are decoded by a small pure-Python decoder (8/16-bit greyscale, non-interlaced) when OpenCV is
+    missing; depth EXRs need OpenEXR and RGB mp4s need imageio -- if those are missing and there is no twin, the
+    reader raises with a message that says so.
+
+Poses are returned as the (F,4,4) matrices stored in the npz (the reference round-trips them through a normalised
+quaternion, vipe/utils/geometry.py:339-344, which changes a valid pose by < 1e-6).
+"""
+from __future__ import annotations
+
+import io as _io
+import struct
+import zipfile
+import zlib
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Iterator, Optional
+
+import numpy as np
+
+
+@dataclass
+class ArtifactPath:
+    base_path: Path
+    artifact_name: str
+
+    @property
+    def rgb_path(self) -> Path:
+        return self.base_path / "rgb" / f"{self.artifact_name}.mp4"
+
+    @property
+    def pose_path(self) -> Path:
+        return self.base_path / "pose" / f"{self.artifact_name}.npz"
+
+    @property
+    def depth_path(self) -> Path:
+        return self.base_path / "depth" / f"{self.artifact_name}.zip"
+
+    @property
+    def intrinsics_path(self) -> Path:
+        return self.base_path / "intrinsics" / f"{self.artifact_name}.npz"
+
+    @property
+    def camera_type_path(self) -> Path:
+        return self.base_path / "intrinsics" / f"{self.artifact_name}_camera.txt"
+
+    @property
+    def mask_path(self) -> Path:
+        return self.base_path / "mask" / f"{self.artifact_name}.zip"
+
+    @classmethod
+    def glob_artifacts(cls, base_path: Path, use_video: bool = False) -> Iterator["ArtifactPath"]:
+        base_path = Path(base_path)
+        if use_video:
+            seen = set()
+            for pat in ("*.mp4", "*.npy"):
+                for p in sorted((base_path / "rgb").glob(pat)):
+                    if p.stem not in seen:
+                        seen.add(p.stem)
+                        yield cls(base_path, p.stem)
+        else:
+            for p in sorted((base_path / "vipe").glob("*_info.pkl")):
+                yield cls(base_path, p.stem.replace("_info", ""))
+
+
+def _twin(path: Path) -> Path:
+    return path.with_suffix(".npy")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def read_pose_artifacts(npz_file_path: Path):
+    """(inds (F,), c2w (F,4,4) float32) -- OpenCV camera-to-world matrices."""
+    data = np.load(npz_file_path)
+    return data["inds"], np.asarray(data["data"], dtype=np.float32)
+
+
+def read_intrinsics_artifacts(intr_file_path: Path, camera_file_path: Optional[Path] = None):
+    """(inds, intrinsics (F,4) float32 [fx,fy,cx,cy], camera type names).  A missing camera-type file means PINHOLE."""
+    data = np.load(intr_file_path)
+    inds, intr = data["inds"], np.asarray(data["data"], dtype=np.float32)
+    if camera_file_path is None or not Path(camera_file_path).exists():
+        assert intr.shape[1] == 4
+        types = ["PINHOLE"] * intr.shape[0]
+    else:
+        with open(camera_file_path) as f:
+            types = [line.split(":")[1].strip() for line in f.readlines() if ":" in line]
+    return inds, intr, types
+
+
+def read_rgb_artifacts(rgb_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
+    """Yields (frame index, (H,W,3) uint8).  (The reference yields uint8/255 as float32; the renderer only ever needs
+    the bytes back: (rgb*255).astype(uint8) is the identity on them.)"""
+    rgb_file_path = Path(rgb_file_path)
+    if rgb_file_path.exists() and rgb_file_path.suffix != ".npy":
+        try:
+            import imageio  # noqa: F401
+        except ImportError as e:
+            if not _twin(rgb_file_path).exists():
+                raise ImportError(f"reading {rgb_file_path} needs imageio (ffmpeg); no {_twin(rgb_file_path).name} "
+                                  "twin found") from e
+        else:
+            reader = imageio.get_reader(rgb_file_path, "ffmpeg")
+            for i, frame in enumerate(reader):
+                yield i, np.asarray(frame, dtype=np.uint8)
+            return
+    tw = rgb_file_path if rgb_file_path.suffix == ".npy" else _twin(rgb_file_path)
+    if not tw.exists():
+        raise FileNotFoundError(str(rgb_file_path))
+    arr = np.load(tw, mmap_mode="r")
+    for i in range(arr.shape[0]):
+        yield i, np.asarray(arr[i], dtype=np.uint8)
+
+
+def read_depth_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
+    """Yields (frame index, (H,W) float32 metric depth).  EXR channel Z is HALF; a frame that fails to load yields NaN."""
+    zip_file_path = Path(zip_file_path)
+    if zip_file_path.exists():
+        try:
+            import OpenEXR
+        except ImportError as e:
+            if not _twin(zip_file_path).exists():
+                raise ImportError(f"reading {zip_file_path} needs OpenEXR; no {_twin(zip_file_path).name} twin "
+                                  "found") from e
+        else:
+            vw = vh = 0
+            with zipfile.ZipFile(zip_file_path, "r") as z:
+                for name in sorted(z.namelist()):
+                    idx = int(name.split(".")[0])
+                    with z.open(name) as f:
+                        try:
+                            exr = OpenEXR.InputFile(f)
+                        except OSError:
+                            assert vw > 0 and vh > 0
+                            yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
+                            continue
+                        dw = exr.header()["dataWindow"]
+                        vw, vh = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
+                        buf = exr.channels(["Z"])[0]
+                        yield idx, np.frombuffer(buf, dtype=np.float16).reshape(vh, vw).astype(np.float32)
+            return
+    tw = _twin(zip_file_path)
+    if not tw.exists():
+        raise FileNotFoundError(str(zip_file_path))
+    arr = np.load(tw, mmap_mode="r")
+    for i in range(arr.shape[0]):
+        yield i, np.asarray(arr[i]).astype(np.float32)
+
+
+def decode_png_gray(buf: bytes) -> np.ndarray:
+    """Minimal PNG decoder: 8- or 16-bit greyscale (colour type 0), non-interlaced."""
+    if buf[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, idat, hdr = 8, [], None
+    while pos < len(buf):
+        n, typ = struct.unpack(">I4s", buf[pos:pos + 8])
+        body = buf[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if ctype != 0 or depth not in (8, 16) or interlace != 0:
+        raise ValueError(f"unsupported PNG (colour type {ctype}, depth {depth}, interlace {interlace}); install opencv")
+    bpp = depth // 8
+    stride = w * bpp
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, stride + 1)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft = int(raw[y, 0])
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, dtype=np.int32)
+            for x in range(stride):
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    p = a
+                elif ft == 3:
+                    p = (a + b) >> 1
+                elif ft == 4:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError("bad PNG filter")
+                cur[x] = (line[x] + p) & 255
+        out[y] = cur
+        prev = cur
+    if depth == 16:
+        o = out.reshape(h, w, 2).astype(np.uint16)
+        return o[..., 0] * 256 + o[..., 1]
+    return out
+
+
+def read_instance_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
+    """Yields (frame index, (H,W) uint8 instance ids), 0 = background."""
+    zip_file_path = Path(zip_file_path)
+    if zip_file_path.exists():
+        try:
+            import cv2
+        except ImportError:
+            cv2 = None
+        with zipfile.ZipFile(zip_file_path, "r") as z:
+            for name in sorted(z.namelist()):
+                idx = int(name.split(".")[0])
+                data = z.read(name)
+                if cv2 is not None:
+                    m = cv2.imdecode(np.frombuffer(data, dtype=np.uint8), cv2.IMREAD_UNCHANGED)
+                else:
+                    m = decode_png_gray(data)
+                yield idx, np.asarray(m).astype(np.uint8)
+        return
+    tw = _twin(zip_file_path)
+    if not tw.exists():
+        raise FileNotFoundError(str(zip_file_path))
+    arr = np.load(tw, mmap_mode="r")
+    for i in range(arr.shape[0]):
+        yield i, np.asarray(arr[i], dtype=np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def encode_png_gray(img: np.ndarray) -> bytes:
+    """8-bit greyscale PNG (filter 0), used to write synthetic instance masks in the reference's container format."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img], axis=1).tobytes()
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w, mask_as_png_zip: bool = True):
+    """Writes a sequence in the ViPE layout using the array twins for rgb and depth (no codec needed) and, by default,
+    the reference's zip-of-PNG container for the instance masks.  depth is stored as float16 like the EXR HALF files."""
+    base = Path(base)
+    depth, rgb, mask = np.asarray(depth), np.asarray(rgb), None if mask is None else np.asarray(mask)
+    Fn = depth.shape[0]
+    for sub in ("rgb", "depth", "pose", "intrinsics", "mask"):
+        (base / sub).mkdir(parents=True, exist_ok=True)
+    np.save(base / "rgb" / f"{name}.npy", rgb.astype(np.uint8))
+    np.save(base / "depth" / f"{name}.npy", depth.astype(np.float16))
+    c2w = np.asarray(c2w, dtype=np.float32)
+    if c2w.ndim == 2:
+        c2w = np.repeat(c2w[None], Fn, axis=0)
+    np.savez(base / "pose" / f"{name}.npz", data=c2w, inds=np.arange(Fn))
+    intr = np.asarray(intr, dtype=np.float32)
+    if intr.ndim == 1:
+        intr = np.repeat(intr[None], Fn, axis=0)
+    np.savez(base / "intrinsics" / f"{name}.npz", data=intr, inds=np.arange(Fn))
+    with open(base / "intrinsics" / f"{name}_camera.txt", "w") as f:
+        for i in range(Fn):
+            f.write(f"{i}: PINHOLE\n")
+    if mask is not None:
+        if mask_as_png_zip:
+            with zipfile.ZipFile(base / "mask" / f"{name}.zip", "w", zipfile.ZIP_DEFLATED) as z:
+                for i in range(Fn):
+                    z.writestr(f"{i:05d}.png", encode_png_gray(mask[i]))
+        else:
+            np.save(base / "mask" / f"{name}.npy", mask.astype(np.uint8))
+    return ArtifactPath(base, name)
+
+
+def write_video(path: Path, frames, fps: int = 30) -> Path:
+    """ego_Prior.mp4 exactly as the reference writes it (imageio, libx264, quality 8, yuv420p; scripts/
+    render_vipe_pointcloud.py:1444) when imageio is importable; otherwise the frames go to <stem>.npy next to the
+    requested path and that path is returned."""
+    path = Path(path)
+    try:
+        import imageio
+    except ImportError:
+        alt = path.with_suffix(".npy")
+        np.save(alt, np.stack([np.asarray(f, dtype=np.uint8) for f in frames], axis=0))
+        return alt
+    with imageio.get_writer(str(path), fps=fps, codec="libx264", quality=8, pixelformat="yuv420p") as w:
+        for f in frames:
+            w.append_data(np.asarray(f, dtype=np.uint8))
+    return path

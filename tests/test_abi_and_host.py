@@ -1,0 +1,194 @@
+"""CPU: the C-ABI library loads and exports every symbol include/egoprior.h declares; argument checks that need no
+GPU; the host-side mirror of the reference's helper functions; artifact readers."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_functions():
+    text = (ROOT / "include" / "egoprior.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(egoprior_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from egoprior import _lib
+    names = declared_functions()
+    assert len(names) >= 20
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/egoprior.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
+    assert _lib.lib().egoprior_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    from egoprior import _lib
+    L = _lib.lib()
+    assert L.egoprior_raster_workspace_bytes(0, 10, 10, 0.1) == 0
+    assert L.egoprior_raster_workspace_bytes(480, 832, 1000, 0.012) > 0
+    assert L.egoprior_unproject_workspace_bytes(1080, 1920, 0) == 0
+    assert L.egoprior_meanbg_state_bytes(4, 5) == 17 * 20 * 4
+    rc = L.egoprior_reliable_depth_mask(None, 4, 4, None, None)
+    assert rc == _lib.E_INVALID and b"NULL" in L.egoprior_last_error()
+    rp = _lib.RasterParams(radius=0.01, radius_sq_w=1e-4, K=21, rotate_cw=0, colors_gt1=1)
+    import ctypes as C
+    rc = L.egoprior_rasterize_composite(C.byref(rp), 8, 8, None, 0, None, None, None, None, None, None, None, None,
+                                        None, None, 0, None)
+    assert rc == _lib.E_INVALID and b"K must be" in L.egoprior_last_error()
+    with pytest.raises(_lib.EgoPriorError):
+        _lib.set_option("no_such_option", 1)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from egoprior.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine("cuda:0")
+
+
+def test_scale_intrinsics_and_radius():
+    from egoprior import render_vipe_pointcloud as rv
+    from egoprior import engine as eng
+    assert rv.scale_intrinsics(100.0, 50.0, 40.0, (200, 100), (100, 50)) == (50.0, 25.0, 20.0)
+    assert rv.scale_intrinsics(10.0, 20.0, 5.0, 6.0, (200, 100), (100, 25)) == (2.5, 10.0, 1.25, 3.0)
+    assert rv.scale_intrinsics(7.0, 1.0, 2.0, (0, 10), (5, 5)) == (7.0, 1.0, 2.0)
+    with pytest.raises(ValueError):
+        rv.scale_intrinsics(1, 2, 3)
+    assert eng.radius_ndc(5.0, 448, 448) == pytest.approx(10 / 448)
+    assert eng.radius_ndc(1e9, 10, 10) == 0.25 and eng.radius_ndc(0.0, 10, 10) == 1e-5
+    with pytest.raises(ValueError):
+        eng.split_w2c(np.eye(3))
+
+
+def test_aria_coefficients(tmp_path):
+    from egoprior import render_vipe_pointcloud as rv, synth
+    rad, tan, thin, f, pp = rv.load_aria_distortion_coeffs(None)
+    assert len(rad) == 6 and len(tan) == 2 and len(thin) == 4 and f is None and pp is None
+    assert rad[0] == -0.02340373583137989
+    fx = synth.load_camera_fixture()
+    p = tmp_path / "online_calibration.jsonl"
+    p.write_text(json.dumps(fx["online_calibration_line0"]) + "\n")
+    rad, tan, thin, f, pp = rv.load_aria_distortion_coeffs(str(p), frame_idx=5)  # out of range -> record 0
+    prm = fx["online_calibration_line0"]["CameraCalibrations"][0]["Projection"]["Params"]
+    assert list(rad) == prm[3:9] and list(tan) == prm[9:11] and list(thin) == prm[11:15]
+    assert f[0] == prm[0] and list(pp) == prm[1:3]
+    p.write_text(json.dumps({"CameraCalibrations": [{"Label": "camera-slam-left"}]}) + "\n")
+    assert rv.load_aria_distortion_coeffs(str(p)) == (None,) * 5
+    p.write_text("")
+    assert rv.load_aria_distortion_coeffs(str(p)) == (None,) * 5
+
+
+def test_meta_json_loading(tmp_path):
+    from egoprior import render_vipe_pointcloud as rv
+    meta = {"test_datasets": [
+        {"exo_path": "./videos/other/exo.mp4", "camera_intrinsics": np.eye(3).tolist(),
+         "camera_extrinsics": np.eye(4)[:3].tolist(), "ego_intrinsics": np.eye(3).tolist(), "ego_extrinsics": []},
+        {"exo_path": "./videos/joker/exo.mp4", "camera_intrinsics": (2 * np.eye(3)).tolist(),
+         "camera_extrinsics": (np.arange(12).reshape(3, 4)).tolist(), "ego_intrinsics": (3 * np.eye(3)).tolist(),
+         "ego_extrinsics": [np.eye(4)[:3].tolist(), (2 * np.eye(4)[:3]).tolist()]}]}
+    p = tmp_path / "meta.json"
+    p.write_text(json.dumps(meta))
+    K, E, Ke, egos = rv.load_camera_params_from_meta(str(p), "vipe_results/joker")
+    assert K.dtype == np.float32 and K[0, 0] == 2 and Ke[1, 1] == 3
+    assert E.shape == (4, 4) and list(E[3]) == [0, 0, 0, 1] and E[2, 3] == 11
+    assert len(egos) == 2 and egos[1][0, 0] == 2 and egos[1].dtype == np.float32
+    with pytest.raises(ValueError):
+        rv.load_camera_params_from_meta(str(p), "vipe_results/nobody")
+
+
+def test_parser_matches_reference_flags():
+    from egoprior import render_vipe_pointcloud as rv
+    a = rv.get_parser().parse_args(["--input_dir", "a/b", "--out_dir", "o", "--meta_json_path", "m", "--end_frame", "48"])
+    assert (a.point_size, a.start_frame, a.batch_size) == (1.0, 0, 8)
+    assert not (a.only_bg or a.use_mean_bg or a.fish_eye_rendering) and a.online_calibration_path is None
+    assert rv.configure_output_directory(a) == "o/b"
+    with pytest.raises(SystemExit):
+        rv.get_parser().parse_args(["--input_dir", "a"])
+
+
+def test_generate_background():
+    from egoprior import render_vipe_pointcloud as rv
+    assert rv.generate_background(4, 3).shape == (3, 4, 3)
+    a = rv.generate_background(4, 3, "uniform_noise", seed=1)
+    assert np.array_equal(a, rv.generate_background(4, 3, "uniform_noise", seed=1)) and a.dtype == np.float32
+    assert rv.generate_background(4, 3, "gaussian_noise").max() <= 1.0
+    with pytest.raises(ValueError):
+        rv.generate_background(4, 3, "plaid")
+
+
+def test_artifact_round_trip_and_frame_range(tmp_path):
+    from egoprior import io as eio, render_vipe_pointcloud as rv, synth
+    d, rgb, m = [t.numpy() for t in synth.make_frames(24, 40, range(3), 3)]
+    art = eio.write_synthetic_artifacts(tmp_path / "clip", "exo", d, rgb, m, synth.exo_intrinsics(24, 40),
+                                        np.eye(4, dtype=np.float32))
+    arts = list(eio.ArtifactPath.glob_artifacts(tmp_path / "clip", use_video=True))
+    assert len(arts) == 1 and arts[0].artifact_name == "exo"
+    got_d = [x for _, x in eio.read_depth_artifacts(art.depth_path)]
+    assert np.array_equal(np.stack(got_d), d)  # float16 storage is lossless for fp16-rounded depth
+    got_m = [x for _, x in eio.read_instance_artifacts(art.mask_path)]  # zip of PNGs through the built-in decoder
+    assert np.array_equal(np.stack(got_m), m)
+    got_c = [x for _, x in eio.read_rgb_artifacts(art.rgb_path)]
+    assert np.array_equal(np.stack(got_c), rgb)
+    inds, poses = eio.read_pose_artifacts(art.pose_path)
+    assert list(inds) == [0, 1, 2] and poses.shape == (3, 4, 4)
+    assert rv.get_inference_frame_range(str(tmp_path / "clip")) == (0, 2)
+
+    class A:
+        start_frame, end_frame = 0, 2
+    rv.validate_frame_range(A, 3, str(tmp_path / "clip"))
+    A.end_frame = 1
+    with pytest.raises(ValueError):
+        rv.validate_frame_range(A, 3, str(tmp_path / "clip"))
+    A.end_frame = 2
+    with pytest.raises(ValueError):
+        rv.validate_frame_range(A, 2, str(tmp_path / "clip"))
+    with pytest.raises(FileNotFoundError):
+        list(eio.read_depth_artifacts(tmp_path / "clip" / "depth" / "missing.zip"))
+
+
+def test_png_decoder_all_filters():
+    import struct
+    import zlib
+    from egoprior import io as eio
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (6, 7), dtype=np.uint8)
+    assert np.array_equal(eio.decode_png_gray(eio.encode_png_gray(img)), img)
+    # hand-encode with filter types 1..4 to exercise the decoder's prediction paths
+    h, w = img.shape
+    rows = []
+    prev = np.zeros(w, np.int32)
+    for y in range(h):
+        ft = 1 + (y % 4)
+        cur = img[y].astype(np.int32)
+        enc = np.zeros(w, np.int32)
+        for x in range(w):
+            a = cur[x - 1] if x else 0
+            b = prev[x]
+            c = prev[x - 1] if x else 0
+            if ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            enc[x] = (cur[x] - p) & 255
+        rows.append(bytes([ft]) + enc.astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b""))
+    assert np.array_equal(eio.decode_png_gray(png), img)

@@ -228,7 +228,8 @@ def main():
         "k_project_count": 32 * n_in_avg,
         "k_tile_scan": 0,
         "k_tile_fill": 16 * n_in_avg,
-        "k_splat": 16 * n_avg + 3 * He * We,
+        "k_splat_sweep": 16 * n_avg + 3 * He * We,
+        "k_splat_bubble": 16 * n_avg + 3 * He * We,
     }
     kernels = {}
     for name, (ms, calls) in kern.items():
@@ -243,8 +244,9 @@ def main():
         k = kernels[dominant]
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k["frac_hbm"], "traffic": None, "avg_us": k["avg_us"],
-                    "note": "k_splat is bound by VALU/LDS work (exact top-20 per pixel), not by HBM; its algorithmic "
-                            "bytes are 16 B per projected point + 3 B per output pixel"}
+                    "note": "the splat kernel is bound by VALU/LDS work (exact top-20 per pixel), not by HBM; its "
+                            "algorithmic bytes are 16 B per projected point + 3 B per output pixel; `traffic` is the "
+                            "PMC figure of profiles/pmc_traffic.json (its tile lists are 16 B per point-tile pair)"}
         tr = ROOT / "profiles" / "pmc_traffic.json"
         if tr.exists():
             try:

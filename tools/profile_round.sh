@@ -1,0 +1,12 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one round: kernel-trace stats of the default bench command and two PMC passes
+# (HBM read / write bytes).  Run on the GPU box: bash tools/profile_round.sh r01
+set -e
+R=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$R
+mkdir -p $OUT
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --skip-cpu > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu > $OUT/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu > $OUT/pmc_write.log 2>&1
+find $OUT -name "*.csv" | head -20

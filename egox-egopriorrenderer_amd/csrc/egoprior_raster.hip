@@ -206,6 +206,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ tile_cursor,
                                                     uint32_t* __restrict__ tile_order, int n_tiles, uint32_t capacity,
                                                     int32_t* __restrict__ d_status) {
+    constexpr int PT = 8;  // tiles per thread and pass
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t ohist[256];
@@ -214,10 +215,16 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     if (tid == 0) carry_s = 0;
     if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int t = base + tid;
-        const uint32_t v = (t < n_tiles) ? tile_count[t] : 0u;
-        uint32_t incl = v;
+    for (int base = 0; base < n_tiles; base += 1024 * PT) {
+        const int t0 = base + tid * PT;
+        uint32_t v[PT];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            v[k] = (t0 + k < n_tiles) ? tile_count[t0 + k] : 0u;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(incl, d);
@@ -228,24 +235,41 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
         uint32_t woff = 0;
         for (int w2 = 0; w2 < wid; ++w2) woff += wave_sums[w2];
         const uint32_t carry = carry_s;
-        if (t < n_tiles) {
-            tile_start[t] = carry + woff + incl - v;
-            tile_cursor[t] = 0u;
-            atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u);
+        uint32_t run = carry + woff + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            if (t0 + k < n_tiles) {
+                tile_start[t0 + k] = run;
+                tile_cursor[t0 + k] = 0u;
+                atomicAdd(&ohist[255u - min(v[k] >> 4, 255u)], 1u);
+            }
+            run += v[k];
         }
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + incl;
+        if (tid == 1023) carry_s = run;
         __syncthreads();
     }
     if (tid == 0) {
         tile_start[n_tiles] = carry_s;
         if (d_status != nullptr) *d_status = (carry_s > capacity) ? 1 : 0;
-        uint32_t run = 0;
-        for (int b = 0; b < 256; ++b) {
-            const uint32_t c = ohist[b];
-            ohist[b] = run;
-            run += c;
+    }
+    // exclusive scan of the 256 length classes (4 waves), then the launch order
+    uint32_t c = 0, incl = 0;
+    if (tid < 256) {
+        c = ohist[tid];
+        incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
+        if (lane == 63) wave_sums[wid] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t woff = 0;
+        for (int w2 = 0; w2 < wid; ++w2) woff += wave_sums[w2];
+        ohist[tid] = woff + incl - c;
     }
     __syncthreads();
     for (int t = tid; t < n_tiles; t += 1024) {
@@ -324,16 +348,25 @@ typedef unsigned long long u64;
 // Diagnostic build only (-DEP_STAMPS): per-phase cycle totals of k_splat_sweep, summed over waves.
 #ifdef EP_STAMPS
 __device__ unsigned long long g_stamps[16];
-#define EP_STAMP_DECL unsigned long long _t0 = clock64(), _t1
-#define EP_STAMP(slot)                                                                    \
-    do {                                                                                  \
-        _t1 = clock64();                                                                  \
-        if (threadIdx.x == 0) atomicAdd(&g_stamps[slot], (unsigned long long)(_t1 - _t0)); \
-        _t0 = _t1;                                                                        \
+// cycles are accumulated in registers and added to the global totals once, at the end of the kernel
+#define EP_STAMP_DECL                    \
+    unsigned long long _t0 = clock64(), _t1; \
+    unsigned long long _acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define EP_STAMP(slot)            \
+    do {                          \
+        _t1 = clock64();          \
+        _acc[slot] += _t1 - _t0;  \
+        _t0 = _t1;                \
+    } while (0)
+#define EP_STAMP_FLUSH()                                                  \
+    do {                                                                  \
+        if (threadIdx.x == 0)                                             \
+            for (int _i = 0; _i < 10; ++_i) atomicAdd(&g_stamps[_i], _acc[_i]); \
     } while (0)
 #else
 #define EP_STAMP_DECL
 #define EP_STAMP(slot)
+#define EP_STAMP_FLUSH()
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -519,9 +552,10 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // entries (C/64 per lane, held in registers while the chunk is organised):
 //   load    : C/64 independent, fully coalesced 16-byte record loads per lane (the tile lists hold index, depth
 //             bits and NDC x, y); records whose key cannot beat the current K-th key of any pixel are dropped
-//   sort    : monotone radix bucketing on (key - min) >> shift into LDS (histogram, scan, scatter: O(n)), then every
-//             lane insertion-sorts the short run of records that fell into its own NB/64 buckets; if some run is
-//             long (many equal depths) the whole chunk is bitonic-sorted instead.  Either way S[] ends up sorted.
+//   sort    : monotone two-level radix bucketing of the keys into LDS (histogram, scan, scatter: O(n)); buckets hold
+//             one or two records each, and every record then ranks itself inside its bucket by counting the smaller
+//             keys there and moves to start + rank.  If some bucket is long (many equal depths) the whole chunk is
+//             bitonic-sorted instead.  Either way S[] ends up sorted.
 //   sweep   : the sorted records are offered front to back, 64 at a time, to all 64 pixels in a branch-free loop
 //             (record coordinates come from v_readlane, i.e. scalar operands) that builds each pixel's 64-bit hit
 //             mask; every lane then appends its hits to its slot list.  Sorted input makes the first K hits of a
@@ -529,7 +563,9 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 //   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
 //             later chunks: compare-exchange insertion).
 // LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
-template <int C, int NB, int WPE>
+// DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
+// the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
+template <int C, int NB, int WPE, int DBG = 0>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -542,7 +578,9 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     constexpr int PER = NB / 64;  // buckets per lane
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
     __shared__ uint32_t bkt[NB];
+    __shared__ uint32_t cinfo[64];
     __shared__ uint16_t slots[EP_K][64];
+    static_assert(NB >= C, "the two-level bucket map uses up to C buckets");
 
     const int tile = (int)tile_order[blockIdx.x];
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
@@ -582,6 +620,18 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             val[u] = e < end;
             rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
         }
+#ifdef EP_DBG_DOUBLE_LOAD
+        // diagnostic: wait for the records, then fetch them a second time (now cache-resident) and keep both alive
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) asm volatile("" ::"v"(rec[u].x));
+        EP_STAMP(8);
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            const uint32_t e = pos + (uint32_t)(u * 64 + lane);
+            const uint4 r2_ = list[val[u] ? e : end - 1u];
+            asm volatile("" ::"v"(r2_.x), "v"(r2_.y), "v"(r2_.z), "v"(r2_.w));
+        }
+#endif
         u64 kmin = ~0ull, kmax = 0ull;
         int m = 0;
 #pragma unroll
@@ -595,23 +645,65 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             m += __popcll(__ballot(val[u]));
         }
         pos += C;
+        if (DBG == 1) {
+            uint32_t cs = 0;
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) cs += rec[u].x ^ rec[u].y ^ rec[u].z ^ rec[u].w;
+            if (cs == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+            continue;
+        }
         if (m == 0) continue;
         EP_STAMP(1);
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
         const u64 range = kmax - kmin;
-        int shift = 0;
-        if (range >= (u64)NB) shift = (64 - __builtin_clzll(range)) - (31 - __builtin_clz((unsigned)NB));
-        // (range >> shift) < NB: range has 64-clz significant bits and NB = 2^b keeps the top b of them
-
-        // ---- bucket: histogram, exclusive scan, scatter into S -----------------------------------------------------
-        __syncthreads();  // previous chunk's readers of S / bkt / slots are done
+        // Two-level monotone bucket map.  Level 1: 64 equal-width ranges of [kmin, kmax], one per lane.  Level 2: range c
+        // that received cc records is cut into 2^floor(log2 cc) equal sub-ranges, so buckets hold one or two records
+        // wherever the keys are locally uniform, however unevenly the 64 ranges are populated (a tile that sees two
+        // surfaces far apart in depth would otherwise crowd all its records into a few equal-width buckets).
+        int cshift = 0;
+        if (range >= 64ull) cshift = (64 - __builtin_clzll(range)) - 6;
+        __syncthreads();  // previous chunk's readers of S / bkt / slots / cinfo are done
+        cinfo[lane] = 0u;
 #pragma unroll
         for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < RPL; ++u)
-            if (val[u]) atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> shift)], 1u);
+            if (val[u]) atomicAdd(&cinfo[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
+        __syncthreads();
+        {
+            const uint32_t cc = cinfo[lane];
+            int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
+            fl = min(fl, cshift);                                 // cannot cut finer than one key value
+            const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
+            uint32_t incl = nf;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            __syncthreads();
+            cinfo[lane] = (incl - nf) | ((uint32_t)fl << 16);  // first bucket of the range | log2(sub-ranges)
+        }
+        __syncthreads();
+        uint32_t bq[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            bq[u] = 0u;
+            if (val[u]) {
+                const u64 d = make_key(rec[u].y, rec[u].x) - kmin;
+                const uint32_t c = (uint32_t)(d >> cshift);
+                const uint32_t info = cinfo[c];
+                const int fl = (int)(info >> 16);
+                bq[u] = (info & 0xFFFFu) + (uint32_t)((d - ((u64)c << cshift)) >> (cshift - fl));
+            }
+        }
+
+        // ---- bucket: histogram, exclusive scan, scatter into S -----------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < RPL; ++u)
+            if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
         __syncthreads();
         {
             uint32_t loc[PER];
@@ -638,7 +730,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
         for (int u = 0; u < RPL; ++u)
             if (val[u]) {
-                const uint32_t p = atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> shift)], 1u);
+                const uint32_t p = atomicAdd(&bkt[bq[u]], 1u);
                 S[p] = rec[u];
             }
         __syncthreads();
@@ -646,23 +738,76 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
             S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
         EP_STAMP(2);
-        // bkt[b] is now the end of bucket b.  This lane's buckets cover S[seg_a, seg_b).
-        const int seg_a = (lane == 0) ? 0 : (int)bkt[lane * PER - 1];
-        const int seg_b = (int)bkt[lane * PER + PER - 1];
-        if (__ballot(seg_b - seg_a > 48) == 0ull) {
-            // records are in bucket order; only records of one bucket can be out of order: short insertion sort
-            for (int i = seg_a + 1; i < seg_b; ++i) {
-                const uint4 cur = S[i];
-                const u64 key = make_key(cur.y, cur.x);
-                int j = i - 1;
-                while (j >= seg_a) {
-                    const uint4 o = S[j];
-                    if (make_key(o.y, o.x) < key) break;
-                    S[j + 1] = o;
-                    --j;
-                }
-                if (j + 1 != i) S[j + 1] = cur;
+        if (DBG == 5) {
+            const uint4 q = S[lane];
+            if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+            continue;
+        }
+        // bkt[b] is now the end of bucket b and S holds the records in bucket order.  Order inside a bucket: every
+        // record (still in this lane's registers) counts the keys of its own bucket that are smaller than its key;
+        // keys are unique, so start + count is its final position.
+        int posf[RPL];
+        int big = 0;
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            posf[u] = -1;
+            if (val[u]) {
+                const int bs = (bq[u] == 0u) ? 0 : (int)bkt[bq[u] - 1u];
+                const int be = (int)bkt[bq[u]];
+                posf[u] = bs;
+                big = max(big, be - bs);
             }
+        }
+#ifdef EP_STAMPS
+        {
+            int mx = big;
+            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            if (threadIdx.x == 0) {
+                atomicAdd(&g_stamps[13], (unsigned long long)(mx > 32));
+                atomicAdd(&g_stamps[14], (unsigned long long)mx);
+            }
+        }
+#endif
+        if (DBG == 6) {
+            // timing probe: leave the records in bucket order (wrong output, same downstream work)
+        } else if (__ballot(big > 32) == 0ull) {
+            // The first 4 keys of the bucket are fetched unconditionally (clamped), 4 records at a time, so that 16
+            // independent LDS reads are in flight together; only buckets with more than 4 records loop.
+#pragma unroll
+            for (int u0 = 0; u0 < RPL; u0 += 4) {
+                uint2 kk[4][4];
+                int bsz[4];
+#pragma unroll
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    const int u = u0 + a4;
+                    const int bs = val[u] ? posf[u] : 0;
+                    const int be = val[u] ? (int)bkt[bq[u]] : 1;
+                    bsz[a4] = be - bs;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kk[a4][j] = *reinterpret_cast<const uint2*>(&S[min(bs + j, be - 1)]);
+                }
+#pragma unroll
+                for (int a4 = 0; a4 < 4; ++a4) {
+                    const int u = u0 + a4;
+                    if (val[u]) {
+                        const u64 key = make_key(rec[u].y, rec[u].x);
+                        int r = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            r += (j < bsz[a4] && make_key(kk[a4][j].y, kk[a4][j].x) < key) ? 1 : 0;
+                        for (int j = 4; j < bsz[a4]; ++j) {
+                            const uint2 k2 = *reinterpret_cast<const uint2*>(&S[posf[u] + j]);
+                            r += (make_key(k2.y, k2.x) < key) ? 1 : 0;
+                        }
+                        posf[u] += r;
+                    }
+                }
+            }
+            __syncthreads();  // every rank is computed before any record moves
+#pragma unroll
+            for (int u = 0; u < RPL; ++u)
+                if (val[u]) S[posf[u]] = rec[u];
         } else {
             // degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk
             for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
@@ -686,6 +831,11 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         }
         __syncthreads();
 
+        if (DBG == 2) {
+            const uint4 q = S[lane];
+            if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+            continue;
+        }
         EP_STAMP(3);
         // ---- sweep front to back ---------------------------------------------------------------------------------
         int cnt = inside ? 0 : K;  // pixels outside the image never take part
@@ -788,6 +938,10 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         }
 #endif
 
+        if (DBG == 3) {
+            if ((uint32_t)(cnt + slots[0][lane]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+            continue;
+        }
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
         const int won = inside ? cnt : 0;
         if (chunk_no == 0) {
@@ -823,8 +977,14 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         EP_STAMP(7);
     }
     EP_STAMP(8);
+    if (DBG != 0 && DBG != 4) return;
+    if (DBG == 4) {  // everything but the compositor
+        if ((kz[0] ^ ki[19]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+        return;
+    }
     if (inside) composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
     EP_STAMP(9);
+    EP_STAMP_FLUSH();
 }
 
 }  // namespace ep
@@ -970,7 +1130,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_SWEEP(64, 64, 2);
             break;
         case 3:
-            EP_SWEEP(512, 256, 3);
+            EP_SWEEP(512, 512, 3);
             break;
         case 4:
             EP_SWEEP(512, 512, 3);
@@ -982,7 +1142,31 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_SWEEP(1024, 1024, 2);
             break;
         case 7:
-            EP_SWEEP(1024, 512, 2);
+            EP_SWEEP(1024, 2048, 2);
+            break;
+        case 10:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 1>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 11:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 2>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 12:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 3>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 14:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 5>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 15:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 6>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 13:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         default:
             EP_SWEEP(1024, 1024, 2);

@@ -29,6 +29,13 @@ cam = eng.pinhole_camera(R, t, synth.ego_pinhole_K(He, We), He, We)
 rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(10):
+    E.render_frame(cam, rp, bg)
+ev1.record()
+torch.cuda.synchronize()
+print(f"render_frame: {ev0.elapsed_time(ev1) / 10 * 1e3:.1f} us per frame (diagnostic build)")
 buf = (C.c_ulonglong * 16)()
 dbg(buf, 1)
 E.render_frame(cam, rp, bg)
@@ -39,4 +46,5 @@ names = ["loop-top", "load", "bucket+scatter", "sort", "mask-build", "append", "
 tot = v[:10].sum()
 for n, x in zip(names, v[:10]):
     print(f"{n:16s} {x:14.0f} cycles  {100 * x / tot:5.1f}%")
+print(f"bitonic fallbacks {v[13]:.0f} of {v[12]:.0f} chunks; mean longest per-lane run {v[14] / max(v[12], 1):.1f}")
 print(f"blocks swept {v[10]:.0f} of {v[11]:.0f} ({100 * v[10] / max(v[11], 1):.1f}%), chunks {v[12]:.0f}, total wave-cycles {tot:.3g}")

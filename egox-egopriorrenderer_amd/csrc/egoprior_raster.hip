@@ -361,7 +361,7 @@ __device__ unsigned long long g_stamps[16];
 #define EP_STAMP_FLUSH()                                                  \
     do {                                                                  \
         if (threadIdx.x == 0)                                             \
-            for (int _i = 0; _i < 10; ++_i) atomicAdd(&g_stamps[_i], _acc[_i]); \
+            for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_stamps[_i], _acc[_i]); \
     } while (0)
 #else
 #define EP_STAMP_DECL
@@ -370,6 +370,9 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+
+#define EP_RANK_SELF 8    // buckets up to this long are ordered by their own records
+#define EP_RANK_WAVE 128  // buckets up to this long are ordered by the wave; longer ones send the chunk to bitonic sort
 
 __device__ __forceinline__ u64 make_key(uint32_t zbits, uint32_t idx) { return ((u64)zbits << 32) | (u64)idx; }
 
@@ -390,6 +393,24 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
         const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
         const u64 o = ((u64)hi << 32) | lo;
         v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Sorts one 64-bit value per lane ascending across the wave (bitonic network over lane exchanges).
+__device__ __forceinline__ u64 wave_sort_u64(u64 v) {
+    const int lane = (int)threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j);
+            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j);
+            const u64 o = ((u64)hi << 32) | lo;
+            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const u64 mn = o < v ? o : v, mx = o < v ? v : o;
+            v = keep_min ? mn : mx;
+        }
     }
     return v;
 }
@@ -565,7 +586,7 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
 // DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
 // the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
-template <int C, int NB, int WPE, int DBG = 0>
+template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = true>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -577,9 +598,12 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
     constexpr int PER = NB / 64;  // buckets per lane
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
-    __shared__ uint32_t bkt[NB];
-    __shared__ uint32_t cinfo[64];
-    __shared__ uint16_t slots[EP_K][64];
+    // The bucket counters are dead once a chunk is sorted and the slot lists are dead once it is merged, so the two share
+    // storage: with C = NB = 1024 a wave needs exactly 20 KiB and eight waves fit a CU's 160 KiB.
+    constexpr int AUXB = (NB * 4 > EP_K * 64 * 2) ? NB * 4 : EP_K * 64 * 2;
+    __shared__ __align__(16) unsigned char aux[AUXB];
+    uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
+    uint16_t(*const slots)[64] = reinterpret_cast<uint16_t(*)[64]>(aux);
     static_assert(NB >= C, "the two-level bucket map uses up to C buckets");
 
     const int tile = (int)tile_order[blockIdx.x];
@@ -656,47 +680,111 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         EP_STAMP(1);
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
-        const u64 range = kmax - kmin;
-        // Two-level monotone bucket map.  Level 1: 64 equal-width ranges of [kmin, kmax], one per lane.  Level 2: range c
-        // that received cc records is cut into 2^floor(log2 cc) equal sub-ranges, so buckets hold one or two records
-        // wherever the keys are locally uniform, however unevenly the 64 ranges are populated (a tile that sees two
-        // surfaces far apart in depth would otherwise crowd all its records into a few equal-width buckets).
-        int cshift = 0;
-        if (range >= 64ull) cshift = (64 - __builtin_clzll(range)) - 6;
-        __syncthreads();  // previous chunk's readers of S / bkt / slots / cinfo are done
-        cinfo[lane] = 0u;
+        // Two-level monotone bucket map: 64 level-1 ranges, one per lane; range c, which received cc records, is cut
+        // into 2^floor(log2 cc) equal sub-ranges, so buckets hold a record or two wherever the keys are locally uniform,
+        // however unevenly the ranges are populated.
+        uint32_t bq[RPL];
+        if (SAMPLED) {
+            // Level-1 boundaries are a sorted sample of the chunk's own keys (one per lane, taken across the whole
+            // chunk): every range then holds about the same number of records whatever the depths look like.
+            u64 sk = ~0ull;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
-        __syncthreads();
+            for (int u = 0; u < RPL; ++u)
+                if (val[u] && (lane & (RPL - 1)) == u) sk = make_key(rec[u].y, rec[u].x);
+            sk = wave_sort_u64(sk);
+            __syncthreads();  // previous chunk's readers of S / bkt / slots are done
+            // S is not in use until the scatter: its first bytes hold the range table meanwhile
+            u64* const spl = reinterpret_cast<u64*>(S);                  // [64] lower bound of range c
+            uint2* const rinf = reinterpret_cast<uint2*>(S) + 64;  // [64] first bucket | last sub-range << 16, scale
+            const u64 rlo = (lane == 0) ? kmin : sk;
+            spl[lane] = rlo;
+            bkt[lane] = 0u;  // the first 64 counters take the level-1 histogram, then all are cleared for level 2
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < RPL; ++u)
-            if (val[u]) atomicAdd(&cinfo[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
-        __syncthreads();
-        {
-            const uint32_t cc = cinfo[lane];
-            int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
-            fl = min(fl, cshift);                                 // cannot cut finer than one key value
-            const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
-            uint32_t incl = nf;
+            for (int u = 0; u < RPL; ++u) {
+                // range = number of boundaries 1..63 that are <= key (records that were filtered out look up key 0)
+                const u64 key = val[u] ? make_key(rec[u].y, rec[u].x) : 0ull;
+                uint32_t r = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (spl[r + step] <= key) r += step;
+                bq[u] = r;
+            }
+#pragma unroll
+            for (int u = 0; u < RPL; ++u)
+                if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
+            __syncthreads();
+            {
+                const uint32_t cc = bkt[lane];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
+                const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)sk, 1);
+                const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(sk >> 32), 1);
+                u64 rhi = ((u64)nhi << 32) | nlo;                  // next range's lower bound ...
+                if (lane == 63 || rhi > kmax) rhi = kmax + 1ull;  // ... or the end of the key range
+                const u64 w = (rhi > rlo) ? rhi - rlo : 1ull;
+                const int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
+                const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
+                uint32_t incl = nf;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                // sub-range of a key = floor((key - lower bound) * nf / w), evaluated in float32: rounding may merge or
+                // shift neighbours but keeps the map monotone, which is all the sort needs
+                rinf[lane] = make_uint2((incl - nf) | ((nf == 0u ? 0u : nf - 1u) << 16),
+                                        __float_as_uint((float)nf / (float)w));
             }
             __syncthreads();
-            cinfo[lane] = (incl - nf) | ((uint32_t)fl << 16);  // first bucket of the range | log2(sub-ranges)
-        }
-        __syncthreads();
-        uint32_t bq[RPL];
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) {
-            bq[u] = 0u;
-            if (val[u]) {
-                const u64 d = make_key(rec[u].y, rec[u].x) - kmin;
+            for (int u = 0; u < RPL; ++u) {
+                const uint32_t r = bq[u];
+                const u64 lo = spl[r];
+                const uint2 info = rinf[r];
+                const u64 d = make_key(rec[u].y, rec[u].x) - lo;
+                const uint32_t sub = min((uint32_t)((float)d * __uint_as_float(info.y)), info.x >> 16);
+                bq[u] = val[u] ? (info.x & 0xFFFFu) + sub : 0u;
+            }
+        } else {
+            // Level 1: 64 equal-width ranges of [kmin, kmax].
+            const u64 range = kmax - kmin;
+            int cshift = 0;
+            if (range >= 64ull) cshift = (64 - __builtin_clzll(range)) - 6;
+            __syncthreads();  // previous chunk's readers of S / bkt / slots are done
+            bkt[lane] = 0u;   // the first 64 counters take the level-1 histogram, then all are cleared for level 2
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RPL; ++u)
+                if (val[u]) atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
+            __syncthreads();
+            uint32_t cinfo;  // lane c: first bucket of range c | log2(sub-ranges) << 16
+            {
+                const uint32_t cc = bkt[lane];
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
+                int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
+                fl = min(fl, cshift);                                 // cannot cut finer than one key value
+                const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
+                uint32_t incl = nf;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                cinfo = (incl - nf) | ((uint32_t)fl << 16);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                // the cross-lane read is made by all lanes (records that were filtered out look up range 0)
+                const u64 d = val[u] ? make_key(rec[u].y, rec[u].x) - kmin : 0ull;
                 const uint32_t c = (uint32_t)(d >> cshift);
-                const uint32_t info = cinfo[c];
+                const uint32_t info = (uint32_t)__shfl((int)cinfo, (int)c);
                 const int fl = (int)(info >> 16);
-                bq[u] = (info & 0xFFFFu) + (uint32_t)((d - ((u64)c << cshift)) >> (cshift - fl));
+                bq[u] = val[u] ? (info & 0xFFFFu) + (uint32_t)((d - ((u64)c << cshift)) >> (cshift - fl)) : 0u;
             }
         }
 
@@ -705,6 +793,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         for (int u = 0; u < RPL; ++u)
             if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
         __syncthreads();
+        uint32_t bigmask = 0u;  // which of this lane's PER buckets hold more than EP_RANK_SELF records
         {
             uint32_t loc[PER];
             uint32_t sum = 0;
@@ -712,6 +801,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             for (int q = 0; q < PER; ++q) {
                 loc[q] = bkt[lane * PER + q];
                 sum += loc[q];
+                bigmask |= (loc[q] > EP_RANK_SELF) ? (1u << q) : 0u;
             }
             uint32_t incl = sum;
 #pragma unroll
@@ -727,12 +817,18 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
         }
         __syncthreads();
+        // From here on only the key half of a record stays in registers; sp[u] remembers where the record went.
+        uint32_t kx[RPL], ky[RPL], sp[RPL];
 #pragma unroll
-        for (int u = 0; u < RPL; ++u)
+        for (int u = 0; u < RPL; ++u) {
+            kx[u] = rec[u].x;
+            ky[u] = rec[u].y;
+            sp[u] = 0u;
             if (val[u]) {
-                const uint32_t p = atomicAdd(&bkt[bq[u]], 1u);
-                S[p] = rec[u];
+                sp[u] = atomicAdd(&bkt[bq[u]], 1u);
+                S[sp[u]] = rec[u];
             }
+        }
         __syncthreads();
         // the sweep reads whole blocks of 64: pad the last block with records that never hit and sort last
         for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
@@ -743,18 +839,23 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
             continue;
         }
-        // bkt[b] is now the end of bucket b and S holds the records in bucket order.  Order inside a bucket: every
-        // record (still in this lane's registers) counts the keys of its own bucket that are smaller than its key;
-        // keys are unique, so start + count is its final position.
+        // bkt[b] is now the end of bucket b and S holds the records in bucket order.  Order inside a bucket:
+        //  - up to EP_RANK_SELF records: every record (still in this lane's registers) counts the keys of its own bucket
+        //    that are smaller than its key; keys are unique, so start + count is its final position;
+        //  - up to EP_RANK_WAVE records: the wave ranks the bucket together afterwards (all pairs: each lane holds up to
+        //    two of its records and every key of the bucket is read once, as a broadcast);
+        //  - anything longer (a long run of equal depths): bitonic sort of the whole chunk.
+        // posf[u] = bucket start | scatter position << 10 | bucket length << 20, sign bit = nothing to place
+        static_assert(C <= 1024, "positions are packed into 10 bits");
         int posf[RPL];
         int big = 0;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            posf[u] = -1;
+            posf[u] = (int)0x80100000u;
             if (val[u]) {
                 const int bs = (bq[u] == 0u) ? 0 : (int)bkt[bq[u] - 1u];
                 const int be = (int)bkt[bq[u]];
-                posf[u] = bs;
+                posf[u] = bs | (int)(sp[u] << 10) | ((be - bs) << 20);
                 big = max(big, be - bs);
             }
         }
@@ -763,51 +864,89 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             int mx = big;
             for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
             if (threadIdx.x == 0) {
-                atomicAdd(&g_stamps[13], (unsigned long long)(mx > 32));
+                atomicAdd(&g_stamps[13], (unsigned long long)(mx > EP_RANK_WAVE));
                 atomicAdd(&g_stamps[14], (unsigned long long)mx);
+                atomicAdd(&g_stamps[8], (unsigned long long)(mx > 4));
+                atomicAdd(&g_stamps[9], (unsigned long long)(mx > EP_RANK_SELF));
+                atomicAdd(&g_stamps[15], (unsigned long long)(mx > 32));
             }
         }
 #endif
         if (DBG == 6) {
             // timing probe: leave the records in bucket order (wrong output, same downstream work)
-        } else if (__ballot(big > 32) == 0ull) {
+        } else if (__ballot(big > (DBG == 7 ? 4096 : EP_RANK_WAVE)) == 0ull) {
             // The first 4 keys of the bucket are fetched unconditionally (clamped), 4 records at a time, so that 16
             // independent LDS reads are in flight together; only buckets with more than 4 records loop.
 #pragma unroll
             for (int u0 = 0; u0 < RPL; u0 += 4) {
                 uint2 kk[4][4];
-                int bsz[4];
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
                     const int u = u0 + a4;
-                    const int bs = val[u] ? posf[u] : 0;
-                    const int be = val[u] ? (int)bkt[bq[u]] : 1;
-                    bsz[a4] = be - bs;
+                    const int bs = posf[u] & 1023, bsz = (posf[u] >> 20) & 2047;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        kk[a4][j] = *reinterpret_cast<const uint2*>(&S[min(bs + j, be - 1)]);
+                        kk[a4][j] = *reinterpret_cast<const uint2*>(&S[bs + min(j, bsz - 1)]);
                 }
 #pragma unroll
                 for (int a4 = 0; a4 < 4; ++a4) {
                     const int u = u0 + a4;
-                    if (val[u]) {
-                        const u64 key = make_key(rec[u].y, rec[u].x);
+                    const int bs = posf[u] & 1023, bsz = (posf[u] >> 20) & 2047;
+                    int fin = -1;  // negative: nothing to place, or left to the wave-wide pass below
+                    if (posf[u] >= 0 && bsz <= EP_RANK_SELF) {
+                        const u64 key = make_key(ky[u], kx[u]);
                         int r = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            r += (j < bsz[a4] && make_key(kk[a4][j].y, kk[a4][j].x) < key) ? 1 : 0;
-                        for (int j = 4; j < bsz[a4]; ++j) {
-                            const uint2 k2 = *reinterpret_cast<const uint2*>(&S[posf[u] + j]);
+                            r += (j < bsz && make_key(kk[a4][j].y, kk[a4][j].x) < key) ? 1 : 0;
+                        for (int j = 4; j < bsz; ++j) {
+                            const uint2 k2 = *reinterpret_cast<const uint2*>(&S[bs + j]);
                             r += (make_key(k2.y, k2.x) < key) ? 1 : 0;
                         }
-                        posf[u] += r;
+                        fin = bs + r;
                     }
+                    posf[u] = (fin < 0) ? -1 : (fin | (posf[u] & (1023 << 10)));
                 }
             }
-            __syncthreads();  // every rank is computed before any record moves
+            // every rank is computed: fetch the other half of each record from where the scatter left it, then move
+            uint2 zw[RPL];
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) zw[u] = *reinterpret_cast<const uint2*>(&S[(posf[u] >> 10) & 1023].z);
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
-                if (val[u]) S[posf[u]] = rec[u];
+                if (posf[u] >= 0) S[posf[u] & 1023] = make_uint4(kx[u], ky[u], zw[u].x, zw[u].y);
+            // wave-wide pass over the long buckets, one after the other (lane L owns buckets L*PER .. L*PER+PER-1)
+            u64 has = __ballot(bigmask != 0u);
+            while (has != 0ull) {
+                const int L = __builtin_ctzll(has);
+                has &= has - 1ull;
+                uint32_t mk = (uint32_t)__builtin_amdgcn_readlane((int)bigmask, L);
+                while (mk != 0u) {
+                    const int b = L * PER + __builtin_ctz(mk);
+                    mk &= mk - 1u;
+                    const int bs = (b == 0) ? 0 : (int)bkt[b - 1];
+                    const int n = (int)bkt[b] - bs;  // EP_RANK_SELF < n <= EP_RANK_WAVE
+                    __syncthreads();
+                    uint4 mine[EP_RANK_WAVE / 64];
+                    int rank[EP_RANK_WAVE / 64];
+#pragma unroll
+                    for (int r = 0; r < EP_RANK_WAVE / 64; ++r) {
+                        mine[r] = S[bs + min(r * 64 + lane, n - 1)];
+                        rank[r] = 0;
+                    }
+                    for (int i = 0; i < n; ++i) {
+                        const uint2 k2 = *reinterpret_cast<const uint2*>(&S[bs + i]);
+                        const u64 ko = make_key(k2.y, k2.x);
+#pragma unroll
+                        for (int r = 0; r < EP_RANK_WAVE / 64; ++r) rank[r] += (ko < make_key(mine[r].y, mine[r].x)) ? 1 : 0;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EP_RANK_WAVE / 64; ++r)
+                        if (r * 64 + lane < n) S[bs + rank[r]] = mine[r];
+                }
+            }
         } else {
             // degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk
             for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
@@ -867,11 +1006,32 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #ifdef EP_STAMPS
             if (threadIdx.x == 0) atomicAdd(&g_stamps[10], 1ull);
 #endif
-            if (__ballot(cnt < K) == 0ull) break;  // every pixel already holds its K nearest of this chunk
+            const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
+            if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
             // Offer records j0 .. j0+63 to every pixel: each record's (x, y) is read from LDS at a wave-uniform
             // address (a broadcast), subtracted and squared as a float pair, and the hit bit is shifted into the
             // pixel's mask.  Slots past m hold NaN coordinates (written by the sort stage), which never hit.
             uint32_t hm_lo = 0u, hm_hi = 0u;
+            if (PIXMAJ && __popcll(act) <= PIXMAJ) {
+                // Few pixels are still open: turn the test around.  Every lane holds one record of the block and the
+                // open pixels are visited one by one (their coordinates travel through scalar registers); the
+                // wave-wide compare result is that pixel's hit mask as it stands and is dropped into its lane.
+                const float2v rxy = *reinterpret_cast<const float2v*>(&S[j0 + lane].z);
+                u64 a = act;
+                while (a != 0ull) {
+                    const int p = __builtin_ctzll(a);
+                    a &= a - 1ull;
+                    float2v pp;
+                    pp.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), p));
+                    pp.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), p));
+                    const float2v dxy = rxy - pp;
+                    const float2v q = dxy * dxy;
+                    const float d2 = q.x + q.y;
+                    const u64 hit = __ballot(d2 < r2);
+                    hm_lo = (lane == p) ? (uint32_t)hit : hm_lo;
+                    hm_hi = (lane == p) ? (uint32_t)(hit >> 32) : hm_hi;
+                }
+            } else
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {  // 16 records per group: all LDS reads first, then the arithmetic
                 float2v rxy[16];
@@ -948,7 +1108,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
             for (int k = 0; k < EP_K; ++k) {
                 if (k < won) {
-                    const uint4 w = S[slots[k][lane]];
+                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[k][lane]]);
                     kz[k] = w.y;
                     ki[k] = w.x;
                 }
@@ -958,7 +1118,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 const bool v = k < won;
                 if (__ballot(v) == 0ull) break;
                 if (v) {
-                    const uint4 w = S[slots[k][lane]];
+                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[k][lane]]);
                     bubble_insert(kz, ki, w.y, w.x);
                 }
             }
@@ -1133,16 +1293,19 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_SWEEP(512, 512, 3);
             break;
         case 4:
-            EP_SWEEP(512, 512, 3);
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 40>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 5:
             EP_SWEEP(256, 256, 4);
             break;
         case 6:
-            EP_SWEEP(1024, 1024, 2);
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 7:
-            EP_SWEEP(1024, 2048, 2);
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 64>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 10:
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 1>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
@@ -1162,6 +1325,10 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             break;
         case 15:
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 6>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
+            break;
+        case 16:
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 7>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 13:

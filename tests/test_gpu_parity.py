@@ -241,6 +241,38 @@ def test_rasterize_known_answers_and_ties(engine, splat_variant):
     assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+@pytest.mark.parametrize("mode", ["narrow_band", "one_depth_plus_outliers", "few_depths"])
+def test_rasterize_clustered_depths(engine, mode, splat_variant):
+    """Depth distributions that defeat equal-width bucketing: a narrow band of depths next to a wide spread, one single
+    depth with two far outliers, and a handful of distinct depths.  These drive the sort stage through its long-bucket
+    paths (wave-wide ranking, bitonic sort of the chunk); the fragments must still be exact."""
+    from egoprior import engine as eng
+    H = W = 32
+    ps = 3.0
+    n = 12000
+    rng = np.random.default_rng({"narrow_band": 11, "one_depth_plus_outliers": 12, "few_depths": 13}[mode])
+    xy = rng.uniform(-1.05, 1.05, (n, 2)).astype(F32)
+    if mode == "narrow_band":
+        z = np.where(rng.random(n) < 0.6, F32(5) + rng.uniform(0, 1e-5, n).astype(F32), rng.uniform(1, 50, n).astype(F32))
+        z[rng.integers(0, n, 100)] = F32(1000)
+    elif mode == "one_depth_plus_outliers":
+        z = np.full(n, 3.25, F32)
+        z[17], z[4242] = F32(0.5), F32(900)
+    else:
+        z = (F32(2) + rng.integers(0, 8, n).astype(F32) * np.spacing(F32(2))).astype(F32)
+    ndc = np.concatenate([xy, z.astype(F32)[:, None]], axis=1).astype(F32)
+    cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    r = O.radius_ndc(ps, H, W)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, 20, "scatter")
+    rp = eng.make_raster_params(ps, H, W, K=20, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, H, W, want_f32=True,
+                                     want_fragments=True)
+    assert res["status"].item() == 0
+    _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+    ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+    assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+
+
 def test_rasterize_empty_and_all_behind(engine):
     from egoprior import engine as eng
     H, W = 40, 56

@@ -24,7 +24,8 @@ exo = synth.exo_w2c()
 T = np.linalg.inv(exo)
 intr, c2w = synth.exo_intrinsics(H, W), np.eye(4, dtype=np.float32)
 bg = E.unproject_frame(d[0], rgb[0], None, intr, c2w, T, subsample=1, select=_lib.SELECT_STATIC)
-R, t = eng.split_w2c(synth.ego_orbit_w2c(300, exo)[12])
+pose = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+R, t = eng.split_w2c(synth.ego_orbit_w2c(300, exo)[pose])
 cam = eng.pinhole_camera(R, t, synth.ego_pinhole_K(He, We), He, We)
 rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
@@ -43,8 +44,9 @@ torch.cuda.synchronize()
 dbg(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 names = ["loop-top", "load", "bucket+scatter", "sort", "mask-build", "append", "sweep-exit", "merge", "exit", "composite"]
-tot = v[:10].sum()
-for n, x in zip(names, v[:10]):
+tot = v[:8].sum()
+for n, x in zip(names, v[:8]):
     print(f"{n:16s} {x:14.0f} cycles  {100 * x / tot:5.1f}%")
 print(f"bitonic fallbacks {v[13]:.0f} of {v[12]:.0f} chunks; mean longest per-lane run {v[14] / max(v[12], 1):.1f}")
+print(f"chunks by largest bucket: >4 {v[8]:.0f}, >8 {v[9]:.0f}, >32 {v[15]:.0f}, >256 (bitonic) {v[13]:.0f}")
 print(f"blocks swept {v[10]:.0f} of {v[11]:.0f} ({100 * v[10] / max(v[11], 1):.1f}%), chunks {v[12]:.0f}, total wave-cycles {tot:.3g}")

@@ -318,3 +318,112 @@ class Engine:
                 _ptr(b.count) if b is not None else None, _ptr(b.flags) if b is not None else None,
                 _ptr(img), _ptr(f32), _ptr(idx), _ptr(zb), _ptr(ds), _ptr(status), _ptr(ws), ws.numel(), _stream()))
         return dict(image=img, image_f32=f32, idx=idx, zbuf=zb, dists=ds, status=status)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# frames in flight
+# ----------------------------------------------------------------------------------------------------------------------
+class FramePipeline:
+    """Renders a sequence of ego frames with several frames in flight on one GPU.
+
+    The frames of the reference's loop (scripts/render_vipe_pointcloud.py:1178-1232) do not depend on one another: each
+    takes the shared static cloud, its own exo frame's dynamic points and its own ego pose.  Consecutive frames are
+    therefore issued round-robin to `slots` HIP streams, each slot with its own dynamic-point buffer, workspaces and
+    status word, so the short single-workgroup scans and the tail of one frame's splat overlap the next frame's
+    front end.  Results are the same bits as rendering the frames one after the other.
+
+        pipe = FramePipeline(engine, static_cloud, rp, He, We, exo_hw=(H, W), subsample=s)
+        for f in frames:
+            pipe.submit(cams[f], out_u8[f], up=unproject_params, depth=depth[f], rgb=rgb[f], mask=mask[f])
+        pipe.finish()          # joins the streams; raises if a tile list overflowed
+
+    Inputs and outputs must stay alive and untouched until finish().  Not thread-safe.
+    """
+
+    def __init__(self, engine: Engine, static: DeviceCloud, rp: RasterParams, He: int, We: int,
+                 exo_hw: Optional[Sequence[int]] = None, subsample: int = 1, slots: int = 4):
+        self.E, self.L = engine, engine.L
+        self.static, self.rp, self.He, self.We = static, rp, int(He), int(We)
+        self.n_slots = max(1, int(slots))
+        dev = engine.device
+        self.dyn_cap = 0
+        self.ws_u = [None] * self.n_slots
+        self.dyns = [None] * self.n_slots
+        if exo_hw is not None:
+            H, W = int(exo_hw[0]), int(exo_hw[1])
+            s = int(subsample)
+            self.dyn_cap = ((H + s - 1) // s) * ((W + s - 1) // s)
+            nb = self.L.egoprior_unproject_workspace_bytes(H, W, s)
+            self.ws_u = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+            self.dyns = [engine.new_cloud(self.dyn_cap) for _ in range(self.n_slots)]
+            self.exo = (H, W, s)
+        n_cap = static.capacity + self.dyn_cap
+        nb = self.L.egoprior_render_workspace_bytes(self.He, self.We, n_cap, rp.radius)
+        self.ws_r = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+        self.status = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            self.main = torch.cuda.current_stream()
+            # slot 0 runs on the stream that was current at construction; the others get streams of their own
+            self.streams = [self.main] + [torch.cuda.Stream(device=dev) for _ in range(self.n_slots - 1)]
+        self._h = [C.c_void_p(st.cuda_stream) for st in self.streams]
+        self._next = 0
+        self._forked = False
+        shape = (self.We, self.He, 3) if rp.rotate_cw else (self.He, self.We, 3)
+        self.image_shape = shape
+
+    def _fork(self):
+        if not self._forked:  # everything queued on the main stream so far happens before the slots' work
+            for st in self.streams[1:]:
+                st.wait_stream(self.main)
+            self._forked = True
+
+    def submit(self, cam: Camera, out_image: torch.Tensor, up: Optional[UnprojectParams] = None,
+               depth: Optional[torch.Tensor] = None, rgb: Optional[torch.Tensor] = None,
+               mask: Optional[torch.Tensor] = None, slot: Optional[int] = None) -> int:
+        """Queues one frame; returns the slot it went to.  With `up`, `depth`, `rgb` (and `mask`) given, the frame's
+        dynamic points are extracted first (same slot, same stream) and rendered together with the static cloud."""
+        if cam.H != self.He or cam.W != self.We:
+            raise ValueError("camera size differs from the pipeline's")
+        if tuple(out_image.shape) != tuple(self.image_shape) or out_image.dtype != torch.uint8 \
+                or not out_image.is_contiguous():
+            raise ValueError(f"out_image must be a contiguous uint8 tensor of shape {tuple(self.image_shape)}")
+        k = self._next % self.n_slots if slot is None else int(slot)
+        if slot is None:
+            self._next += 1
+        with torch.cuda.device(self.E.device):
+            return self._submit(k, cam, out_image, up, depth, rgb, mask)
+
+    def _submit(self, k, cam, out_image, up, depth, rgb, mask) -> int:
+        self._fork()
+        d = None
+        if up is not None:
+            if self.dyns[k] is None:
+                raise ValueError("the pipeline was built without exo_hw")
+            H, W, s = self.exo
+            if (up.H, up.W, up.subsample) != (H, W, s) or tuple(depth.shape) != (H, W) \
+                    or tuple(rgb.shape) != (H, W, 3) or (mask is not None and tuple(mask.shape) != (H, W)):
+                raise ValueError("exo frame does not match the pipeline's exo_hw / subsample")
+            d = self.dyns[k]
+            check(self.L.egoprior_unproject_frame(C.byref(up), _ptr(depth), _ptr(rgb), _ptr(mask), _ptr(d.points), None,
+                                                  _ptr(d.count), _ptr(d.flags), _ptr(self.ws_u[k]),
+                                                  self.ws_u[k].numel(), self._h[k]))
+        a = self.static
+        check(self.L.egoprior_render_frame(
+            C.byref(cam), C.byref(self.rp), _ptr(a.points), a.capacity, _ptr(a.count), _ptr(a.flags),
+            _ptr(d.points) if d is not None else None, d.capacity if d is not None else 0,
+            _ptr(d.count) if d is not None else None, _ptr(d.flags) if d is not None else None,
+            _ptr(out_image), None, None, None, None, C.c_void_p(self.status.data_ptr() + 4 * k),
+            _ptr(self.ws_r[k]), self.ws_r[k].numel(), self._h[k]))
+        return k
+
+    def join(self) -> None:
+        """The main stream continues after everything queued on the slots' streams (no host synchronisation)."""
+        for st in self.streams[1:]:
+            self.main.wait_stream(st)
+        self._forked = False
+
+    def finish(self) -> None:
+        self.join()
+        self.main.synchronize()
+        if int(self.status.abs().sum().item()) != 0:
+            raise RuntimeError("tile lists overflowed their workspace (status != 0)")

@@ -330,6 +330,52 @@ def test_render_frame_end_to_end(engine, fisheye, splat_variant):
         assert (np.abs(diff).max(axis=2) > 1).mean() < 2e-3
 
 
+@pytest.mark.parametrize("slots", [1, 3])
+def test_frame_pipeline_matches_one_frame_at_a_time(engine, slots):
+    """Frames in flight on several HIP streams give the same bits as render_frame called frame by frame, and the first
+    frame equals the oracle's."""
+    from egoprior import _lib
+    from egoprior import engine as eng
+    F, H, W, He, We = 7, 120, 208, 96, 160
+    clip = synthetic_clip(H, W, F)
+    dev = engine.device
+    depth = torch.from_numpy(clip["depth"]).to(dev)
+    rgb = torch.from_numpy(clip["rgb"]).to(dev)
+    mask = torch.from_numpy(clip["mask"]).to(dev)
+    bg = engine.unproject_frame(depth[0], rgb[0], mask[0], clip["intr"], clip["c2w"], clip["T"], subsample=1,
+                                select=_lib.SELECT_STATIC)
+    rp = eng.make_raster_params(4.0, He, We, K=20, rotate_cw=True, colors_gt1=-1)
+    up = eng.make_unproject_params(H, W, 1, _lib.SELECT_DYNAMIC, clip["intr"], clip["c2w"], clip["T"])
+    K = np.array([[0.8 * We, 0, We / 2], [0, 0.8 * We, He / 2], [0, 0, 1]], dtype=F32)
+    cams = []
+    for f in range(F):
+        R, t = eng.split_w2c(clip["egos"][f])
+        cams.append(eng.pinhole_camera(R, t, K, He, We))
+    ref = []
+    for f in range(F):
+        dyn = engine.unproject_frame(depth[f], rgb[f], mask[f], clip["intr"], clip["c2w"], clip["T"], subsample=1,
+                                     select=_lib.SELECT_DYNAMIC)
+        ref.append(engine.render_frame(cams[f], rp, bg, dyn)["image"].cpu().numpy())
+    out = torch.zeros((F, We, He, 3), dtype=torch.uint8, device=dev)
+    pipe = eng.FramePipeline(engine, bg, rp, He, We, exo_hw=(H, W), subsample=1, slots=slots)
+    for rep in range(2):  # the second round reuses every slot's buffers
+        out.zero_()
+        for f in range(F):
+            pipe.submit(cams[f], out[f], up=up, depth=depth[f], rgb=rgb[f], mask=mask[f])
+        pipe.finish()
+        got = out.cpu().numpy()
+        for f in range(F):
+            assert np.array_equal(got[f], ref[f]), f"frame {f} differs (round {rep})"
+    assert len({r.tobytes() for r in ref}) > 1  # the frames really differ from one another
+    # frame 0 against the oracle
+    sp, sc = O.unproject_frame(clip["depth"][0], clip["rgb"][0], clip["mask"][0], clip["intr"], clip["c2w"], clip["T"], 1,
+                               "static")
+    dp, dc = O.unproject_frame(clip["depth"][0], clip["rgb"][0], clip["mask"][0], clip["intr"], clip["c2w"], clip["T"], 1,
+                               "dynamic")
+    img = O.render_points_pinhole(np.vstack([sp, dp]), np.vstack([sc, dc]), K, clip["egos"][0], We, He, 4.0)
+    assert np.array_equal(ref[0], img)
+
+
 @pytest.mark.parametrize("F", [1, 5, 17, 40])
 def test_mean_background(engine, F):
     from egoprior import _lib

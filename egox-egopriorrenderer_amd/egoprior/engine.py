@@ -346,30 +346,36 @@ class FramePipeline:
         self.static, self.rp, self.He, self.We = static, rp, int(He), int(We)
         self.n_slots = max(1, int(slots))
         dev = engine.device
-        self.dyn_cap = 0
-        self.ws_u = [None] * self.n_slots
-        self.dyns = [None] * self.n_slots
-        if exo_hw is not None:
-            H, W = int(exo_hw[0]), int(exo_hw[1])
-            s = int(subsample)
-            self.dyn_cap = ((H + s - 1) // s) * ((W + s - 1) // s)
-            nb = self.L.egoprior_unproject_workspace_bytes(H, W, s)
-            self.ws_u = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
-            self.dyns = [engine.new_cloud(self.dyn_cap) for _ in range(self.n_slots)]
-            self.exo = (H, W, s)
-        n_cap = static.capacity + self.dyn_cap
-        nb = self.L.egoprior_render_workspace_bytes(self.He, self.We, n_cap, rp.radius)
-        self.ws_r = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
         self.status = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             self.main = torch.cuda.current_stream()
             # slot 0 runs on the stream that was current at construction; the others get streams of their own
             self.streams = [self.main] + [torch.cuda.Stream(device=dev) for _ in range(self.n_slots - 1)]
+        self.exo = None
+        self.dyn_cap = 0
+        self.ws_u = [None] * self.n_slots
+        self.dyns = [None] * self.n_slots
+        self.ws_r = None
+        self._size_buffers(None if exo_hw is None else (int(exo_hw[0]), int(exo_hw[1]), int(subsample)))
         self._h = [C.c_void_p(st.cuda_stream) for st in self.streams]
         self._next = 0
         self._forked = False
         shape = (self.We, self.He, 3) if rp.rotate_cw else (self.He, self.We, 3)
         self.image_shape = shape
+
+    def _size_buffers(self, exo) -> None:
+        """(Re)allocates the per-slot buffers for exo frames of size exo = (H, W, subsample), or for none."""
+        dev = self.E.device
+        if exo is not None:
+            H, W, s = exo
+            self.dyn_cap = ((H + s - 1) // s) * ((W + s - 1) // s)
+            nb = self.L.egoprior_unproject_workspace_bytes(H, W, s)
+            self.ws_u = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
+            self.dyns = [self.E.new_cloud(self.dyn_cap) for _ in range(self.n_slots)]
+            self.exo = exo
+        nb = self.L.egoprior_render_workspace_bytes(self.He, self.We, self.static.capacity + self.dyn_cap,
+                                                    self.rp.radius)
+        self.ws_r = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(self.n_slots)]
 
     def _fork(self):
         if not self._forked:  # everything queued on the main stream so far happens before the slots' work
@@ -379,9 +385,11 @@ class FramePipeline:
 
     def submit(self, cam: Camera, out_image: torch.Tensor, up: Optional[UnprojectParams] = None,
                depth: Optional[torch.Tensor] = None, rgb: Optional[torch.Tensor] = None,
-               mask: Optional[torch.Tensor] = None, slot: Optional[int] = None) -> int:
+               mask: Optional[torch.Tensor] = None, slot: Optional[int] = None, after_main: bool = False) -> int:
         """Queues one frame; returns the slot it went to.  With `up`, `depth`, `rgb` (and `mask`) given, the frame's
-        dynamic points are extracted first (same slot, same stream) and rendered together with the static cloud."""
+        dynamic points are extracted first (same slot, same stream) and rendered together with the static cloud.
+        `after_main`: the frame's inputs were produced by work queued on the main stream since the last submit (an
+        upload, say), so the slot's stream waits for the main stream first."""
         if cam.H != self.He or cam.W != self.We:
             raise ValueError("camera size differs from the pipeline's")
         if tuple(out_image.shape) != tuple(self.image_shape) or out_image.dtype != torch.uint8 \
@@ -391,14 +399,19 @@ class FramePipeline:
         if slot is None:
             self._next += 1
         with torch.cuda.device(self.E.device):
+            if after_main and k > 0:
+                self.streams[k].wait_stream(self.main)
             return self._submit(k, cam, out_image, up, depth, rgb, mask)
 
     def _submit(self, k, cam, out_image, up, depth, rgb, mask) -> int:
         self._fork()
         d = None
         if up is not None:
-            if self.dyns[k] is None:
-                raise ValueError("the pipeline was built without exo_hw")
+            if self.exo is None:  # first exo frame of a pipeline built without exo_hw: drain, then size the buffers
+                self.join()
+                self.main.synchronize()
+                self._size_buffers((int(up.H), int(up.W), int(up.subsample)))
+                self._fork()
             H, W, s = self.exo
             if (up.H, up.W, up.subsample) != (H, W, s) or tuple(depth.shape) != (H, W) \
                     or tuple(rgb.shape) != (H, W, 3) or (mask is not None and tuple(mask.shape) != (H, W)):

@@ -303,6 +303,16 @@ def render_points_pytorch3d(points_world, colors_world, K, T_c2w=None, T_w2c=Non
                             noise_range=(0, 255), seed=42, _cloud=None, _dyn=None):
     """One pinhole ego frame, uint8, rotated 90 degrees clockwise ((W,H,3)); (H,W,3) background when no point
     survives the finite / |p| < 1e6 filters."""
+    cam, rp = _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size, background_mode, background_color)
+    E = _engine()
+    cloud = _cloud if _cloud is not None else _upload(points_world, colors_world)
+    if cloud.n() + (_dyn.n() if _dyn is not None else 0) == 0:
+        return (_background_u8(W, H, background_mode, background_color, noise_range, seed) * 255).astype(np.uint8)
+    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+
+
+def _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size, background_mode="solid", background_color=(0.0, 0.0, 0.0)):
+    """Argument checks and camera / raster parameters of render_points_pytorch3d (same assertions, same order)."""
     if T_w2c is None:
         assert T_c2w is not None, "Provide either T_w2c or T_c2w."
         T_w2c = np.linalg.inv(T_c2w)
@@ -312,13 +322,7 @@ def render_points_pytorch3d(points_world, colors_world, K, T_c2w=None, T_w2c=Non
     assert np.isfinite(t_cv).all(), "t has NaN/Inf"
     assert np.isfinite(np.asarray(K)).all(), "K has NaN/Inf"
     _check_bg(background_mode, background_color)
-    E = _engine()
-    cloud = _cloud if _cloud is not None else _upload(points_world, colors_world)
-    if cloud.n() + (_dyn.n() if _dyn is not None else 0) == 0:
-        return (_background_u8(W, H, background_mode, background_color, noise_range, seed) * 255).astype(np.uint8)
-    cam = _eng.pinhole_camera(R_cv, t_cv, K, H, W)
-    rp = _eng.make_raster_params(point_size, H, W, K=20, rotate_cw=True)
-    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+    return _eng.pinhole_camera(R_cv, t_cv, K, H, W), _eng.make_raster_params(point_size, H, W, K=20, rotate_cw=True)
 
 
 def render_points_fisheye(points_world, colors_world, T_w2c, ego_intrinsics, W=640, H=480, point_size=2,
@@ -336,6 +340,15 @@ def render_points_fisheye(points_world, colors_world, T_w2c, ego_intrinsics, W=6
     cloud = _cloud if _cloud is not None else _upload(points_world, colors_world)
     if cloud.n() + (_dyn.n() if _dyn is not None else 0) == 0:
         return (_background_u8(W, H, background_mode, background_color, noise_range, seed) * 255).astype(np.uint8)
+    cam, rp = _fisheye_setup(R_cv, t_cv, ego_intrinsics, W, H, point_size, radial_distortion_coeffs,
+                             tangential_distortion_coeffs, thinPrism_distortion_coeffs, focal_length, principal_point,
+                             original_image_size)
+    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+
+
+def _fisheye_setup(R_cv, t_cv, ego_intrinsics, W, H, point_size, radial_distortion_coeffs, tangential_distortion_coeffs,
+                   thinPrism_distortion_coeffs, focal_length, principal_point, original_image_size):
+    """Camera / raster parameters of render_points_fisheye (same checks)."""
     for name, c in (("radial_distortion_coeffs", radial_distortion_coeffs),
                     ("tangential_distortion_coeffs", tangential_distortion_coeffs),
                     ("thinPrism_distortion_coeffs", thinPrism_distortion_coeffs)):
@@ -349,8 +362,7 @@ def render_points_fisheye(points_world, colors_world, T_w2c, ego_intrinsics, W=6
         f, cx, cy = ego_intrinsics[0, 0], ego_intrinsics[0, 2], ego_intrinsics[1, 2]
     cam = _eng.fisheye_camera(R_cv, t_cv, f, cx, cy, radial_distortion_coeffs, tangential_distortion_coeffs,
                               thinPrism_distortion_coeffs, H, W)
-    rp = _eng.make_raster_params(point_size, H, W, K=20, rotate_cw=False)
-    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+    return cam, _eng.make_raster_params(point_size, H, W, K=20, rotate_cw=False)
 
 
 def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.ndarray,
@@ -376,27 +388,79 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
     bg = _upload(bg_points_3d, bg_colors)  # uploaded and filtered once; the filters are per point
     want_dyn = (not only_bg) and artifact_path is not None and T_cam_to_world is not None
     frames = _frames(artifact_path, tolerant=False) if want_dyn else None
-    out = []
-    for frame_idx, T_w2c in enumerate(ego_extrinsics_list):
-        dyn = None
-        if want_dyn:
-            item = next(frames, None)
+
+    def camera(T_w2c):
+        if use_fisheye:
+            T = np.asarray(T_w2c)
+            R_cv, t_cv = _eng.split_w2c(T)
+            assert np.isfinite(R_cv).all(), "R has NaN/Inf"
+            assert np.isfinite(t_cv).all(), "t has NaN/Inf"
+            return _fisheye_setup(R_cv, t_cv, ego_intrinsics, width, height, point_size, rad, tan, thin, foc, pp,
+                                  aria_size)
+        return _pinhole_setup(ego_intrinsics, None, T_w2c, width, height, point_size)
+
+    if bg.n() == 0:
+        # Without static points a frame may end up empty, which the reference answers with an unrotated background
+        # image: that needs each frame's point count on the host, so these frames are rendered one at a time.
+        out = []
+        for frame_idx, T_w2c in enumerate(ego_extrinsics_list):
+            dyn = None
+            item = next(frames, None) if want_dyn else None
             if item is not None:
                 c2w, rgb, intr, ct, depth, mask = item
                 if depth is not None and mask is not None:
                     _check_pinhole(ct)
                     dyn = E.unproject_frame(depth, rgb, mask, intr, c2w, T_cam_to_world, subsample=2,
                                             select=_lib.SELECT_DYNAMIC)
-        if use_fisheye:
-            img = render_points_fisheye(None, None, T_w2c, ego_intrinsics, W=width, H=height, point_size=point_size,
-                                        radial_distortion_coeffs=rad, tangential_distortion_coeffs=tan,
-                                        thinPrism_distortion_coeffs=thin, focal_length=foc, principal_point=pp,
-                                        original_image_size=aria_size, _cloud=bg, _dyn=dyn)
+            if use_fisheye:
+                img = render_points_fisheye(None, None, T_w2c, ego_intrinsics, W=width, H=height,
+                                            point_size=point_size, radial_distortion_coeffs=rad,
+                                            tangential_distortion_coeffs=tan, thinPrism_distortion_coeffs=thin,
+                                            focal_length=foc, principal_point=pp, original_image_size=aria_size,
+                                            _cloud=bg, _dyn=dyn)
+            else:
+                img = render_points_pytorch3d(None, None, K=ego_intrinsics, T_w2c=T_w2c, W=width, H=height,
+                                              point_size=point_size, _cloud=bg, _dyn=dyn)
+            out.append(img)
+        return out
+
+    # The static cloud is not empty, so no frame is: frames go through the pipeline with several of them in flight and
+    # come back to the host together at the end.
+    import torch
+    pipe = None
+    images = None
+    keep = []  # uploaded exo frames stay alive until the pipeline has finished with them
+    for frame_idx, T_w2c in enumerate(ego_extrinsics_list):
+        cam, rp = camera(T_w2c)
+        item = next(frames, None) if want_dyn else None
+        dyn_in = None
+        if item is not None:
+            c2w, rgb, intr, ct, depth, mask = item
+            if depth is not None and mask is not None:
+                _check_pinhole(ct)
+                d = E.to_device(depth, torch.float32)
+                dyn_in = (d, E.to_device(rgb, torch.uint8), E.to_device(mask, torch.uint8),
+                          _eng.make_unproject_params(d.shape[0], d.shape[1], 2, _lib.SELECT_DYNAMIC, intr, c2w,
+                                                     T_cam_to_world))
+        if pipe is None:
+            pipe = _eng.FramePipeline(E, bg, rp, height, width,
+                                      exo_hw=tuple(dyn_in[0].shape) if dyn_in is not None else None, subsample=2)
+            images = torch.empty((num_frames,) + tuple(pipe.image_shape), dtype=torch.uint8, device=E.device)
+        if dyn_in is not None:
+            keep.append(dyn_in)
+            pipe.submit(cam, images[frame_idx], up=dyn_in[3], depth=dyn_in[0], rgb=dyn_in[1], mask=dyn_in[2],
+                        after_main=True)
         else:
-            img = render_points_pytorch3d(None, None, K=ego_intrinsics, T_w2c=T_w2c, W=width, H=height,
-                                          point_size=point_size, _cloud=bg, _dyn=dyn)
-        out.append(img)
-    return out
+            pipe.submit(cam, images[frame_idx])
+        if len(keep) >= 4 * pipe.n_slots:  # bound the device memory held by uploaded frames
+            pipe.join()
+            torch.cuda.current_stream(E.device).synchronize()
+            keep.clear()
+    if pipe is None:
+        return []
+    pipe.finish()
+    host = images.cpu().numpy()
+    return [host[i] for i in range(num_frames)]
 
 
 # ----------------------------------------------------------------------------------------------------------------------

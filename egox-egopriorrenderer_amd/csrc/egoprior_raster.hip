@@ -369,6 +369,11 @@ __device__ unsigned long long g_stamps[16];
 #define EP_STAMP_FLUSH()
 #endif
 
+#ifdef EP_TILE_TIMES
+// Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
+__device__ uint32_t g_tile_times[8192 * 4];
+#endif
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 #define EP_RANK_SELF 8    // buckets up to this long are ordered by their own records
@@ -632,6 +637,10 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     if (pos > end) pos = end;
     int chunk_no = 0;
     EP_STAMP_DECL;
+#ifdef EP_TILE_TIMES
+    const unsigned long long tt0 = __builtin_readcyclecounter();
+    const uint32_t tt_records = end - pos;
+#endif
 
     while (pos < end) {
         EP_STAMP(0);
@@ -832,7 +841,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         __syncthreads();
         // the sweep reads whole blocks of 64: pad the last block with records that never hit and sort last
         for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
-            S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
+            S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
         EP_STAMP(2);
         if (DBG == 5) {
             const uint4 q = S[lane];
@@ -949,7 +958,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
         } else {
             // degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk
-            for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FC00000u, 0x7FC00000u);
+            for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
             __syncthreads();
             for (int k2 = 2; k2 <= C; k2 <<= 1) {
                 for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -1010,7 +1019,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
             // Offer records j0 .. j0+63 to every pixel: each record's (x, y) is read from LDS at a wave-uniform
             // address (a broadcast), subtracted and squared as a float pair, and the hit bit is shifted into the
-            // pixel's mask.  Slots past m hold NaN coordinates (written by the sort stage), which never hit.
+            // pixel's mask.  Slots past m hold infinite coordinates (written by the sort stage), which never hit.
             uint32_t hm_lo = 0u, hm_hi = 0u;
             if (PIXMAJ && __popcll(act) <= PIXMAJ) {
                 // Few pixels are still open: turn the test around.  Every lane holds one record of the block and the
@@ -1038,13 +1047,16 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
                 for (int t = 0; t < 16; ++t) rxy[t] = *reinterpret_cast<const float2v*>(&S[j0 + g4 * 16 + t].z);
                 __builtin_amdgcn_sched_barrier(0);
+                // d2 < r2 exactly when d2 - r2 is negative (the difference of two floats is zero only if they are equal;
+                // record coordinates are never NaN with the sign bit set): its sign bit is shifted into the mask.  The
+                // records go in last to first, so record t of the group ends up in bit t.
                 uint32_t bits = 0u;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 15; t >= 0; --t) {
                     const float2v dxy = rxy[t] - pxy;
                     const float2v q = dxy * dxy;
                     const float d2 = q.x + q.y;
-                    bits |= (d2 < r2) ? (1u << t) : 0u;
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d2 - r2), 31);
                 }
                 if (g4 < 2)
                     hm_lo |= bits << (16 * g4);
@@ -1113,14 +1125,51 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     ki[k] = w.x;
                 }
             }
-        } else {
-            for (int k = 0; k < K; ++k) {
-                const bool v = k < won;
-                if (__ballot(v) == 0ull) break;
-                if (v) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[k][lane]]);
-                    bubble_insert(kz, ki, w.y, w.x);
+        } else if (__ballot(won > 0) != 0ull) {
+            // Both lists are sorted: merge them with a fixed compare-exchange network.  Padded to 32 entries with
+            // "nothing" keys, L[i] = min(A[i], B[31 - i]) holds the 32 smallest of both lists as a bitonic sequence; five
+            // half-cleaner stages sort it and its first EP_K entries are the new running list.
+            uint32_t lz[32], li[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int kb = 31 - i;  // B's partner of A[i]
+                uint32_t bz = 0xFFFFFFFFu, bi = 0xFFFFFFFFu;
+                if (kb < EP_K) {
+                    // slots past `won` hold stale bits: the mask keeps the read inside S, the value is dropped
+                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[kb][lane] & (C - 1)]);
+                    bz = (kb < won) ? w.y : 0xFFFFFFFFu;
+                    bi = (kb < won) ? w.x : 0xFFFFFFFFu;
                 }
+                if (i >= EP_K) {
+                    lz[i] = bz;
+                    li[i] = bi;
+                } else if (kb >= EP_K) {
+                    lz[i] = kz[i];
+                    li[i] = ki[i];
+                } else {
+                    const bool lt = make_key(bz, bi) < make_key(kz[i], ki[i]);
+                    lz[i] = lt ? bz : kz[i];
+                    li[i] = lt ? bi : ki[i];
+                }
+            }
+#pragma unroll
+            for (int j = 16; j >= 1; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    if ((i & j) == 0) {
+                        const bool sw = make_key(lz[i | j], li[i | j]) < make_key(lz[i], li[i]);
+                        const uint32_t az = lz[i], ai = li[i];
+                        lz[i] = sw ? lz[i | j] : az;
+                        li[i] = sw ? li[i | j] : ai;
+                        lz[i | j] = sw ? az : lz[i | j];
+                        li[i | j] = sw ? ai : li[i | j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < EP_K; ++k) {
+                kz[k] = lz[k];
+                ki[k] = li[k];
             }
         }
         ++chunk_no;
@@ -1143,6 +1192,14 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         return;
     }
     if (inside) composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+#ifdef EP_TILE_TIMES
+    if (lane == 0 && blockIdx.x < 8192u) {
+        g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile;
+        g_tile_times[blockIdx.x * 4 + 1] = tt_records;
+        g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);
+        g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;
+    }
+#endif
     EP_STAMP(9);
     EP_STAMP_FLUSH();
 }
@@ -1445,6 +1502,12 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);
 }
+
+#ifdef EP_TILE_TIMES
+extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_tile_times), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
+}
+#endif
 
 #ifdef EP_STAMPS
 extern "C" int egoprior_debug_stamps(unsigned long long* host16, int reset) {

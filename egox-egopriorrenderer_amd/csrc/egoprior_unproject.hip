@@ -98,6 +98,130 @@ __global__ void __launch_bounds__(256) k_reliable_flags(const float* __restrict_
     flags[(size_t)j * Ws + i] = ok ? 1 : 0;
 }
 
+// Subsample factors 1 and 2: 64 x 16 samples per block, four horizontally adjacent samples per thread.  A thread pulls
+// each of its five window rows out of the LDS tile once, as 16-byte reads, and feeds all four windows from registers, so a
+// sample costs 2.5 (S=1) or 3.75 (S=2) LDS reads instead of 25.  Same arithmetic, tap by tap, as reliable_at().
+template <int S>
+__global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __restrict__ depth,
+                                                             const uint8_t* __restrict__ mask, int H, int W, int Hs,
+                                                             int Ws, int select, uint8_t* __restrict__ flags) {
+    constexpr int BX = 64, BY = 16;
+    constexpr int FW = (BX - 1) * S + 5, FH = (BY - 1) * S + 5;
+    constexpr int TS = (FW + 3) & ~3;   // row stride in floats, a multiple of 4 so that every thread's reads are aligned
+    constexpr int RW = 3 * S + 5;       // floats of one window row that a thread's four samples touch
+    constexpr int RV = (RW + 3) / 4;    // ... in 16-byte reads
+    static_assert(4 * (BX / 4 - 1) * S + 4 * RV <= TS, "row reads stay inside the tile row");
+    __shared__ __align__(16) float tile[TS * FH];
+    const int i0 = blockIdx.x * BX, j0 = blockIdx.y * BY;
+    {
+        // all of a thread's footprint loads are issued before the first of them is stored to LDS
+        constexpr int NL = (TS * FH + 255) / 256;
+        const int x0 = i0 * S - 2, y0 = j0 * S - 2;
+        float tmp[NL];
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = min((int)threadIdx.x + q * 256, TS * FH - 1);
+            const int ly = e / TS, lx = e - ly * TS;
+            int yy = y0 + ly, xx = x0 + lx;
+            yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            tmp[q] = depth[(size_t)yy * W + xx];
+        }
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = (int)threadIdx.x + q * 256;
+            if (e < TS * FH) tile[e] = tmp[q];
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = i0 + 4 * tx, j = j0 + ty;
+    const int v = j * S;  // image row of the samples; sample k sits at image column (i + k) * S
+    float mx[4], mn[4], acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mx[k] = -INFINITY;
+        mn[k] = INFINITY;
+        acc[k] = 0.0f;
+    }
+    float centre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // all four windows inside the image?  (wave-uniform decision: one code path per wave)
+    const bool interior = (v >= 2) && (v + 2 < H) && (i * S >= 2) && ((i + 3) * S + 2 < W);
+    const bool fast = __ballot(!interior) == 0ull;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+        float row[4 * RV];
+        const float4* src = reinterpret_cast<const float4*>(&tile[(ty * S + kh) * TS + 4 * tx * S]);
+#pragma unroll
+        for (int q = 0; q < RV; ++q) {
+            const float4 t = src[q];
+            row[4 * q + 0] = t.x;
+            row[4 * q + 1] = t.y;
+            row[4 * q + 2] = t.z;
+            row[4 * q + 3] = t.w;
+        }
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    const float d = row[k * S + kw];
+                    mx[k] = fmaxf(mx[k], d);
+                    mn[k] = fminf(mn[k], d);
+                    acc[k] = acc[k] + d;
+                }
+            }
+        } else {
+            const int yy = v + kh - 2;
+            const bool rowin = (yy >= 0) && (yy < H);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    const int xx = (i + k) * S + kw - 2;
+                    if (rowin && xx >= 0 && xx < W) {  // taps outside the image: skipped by max/min, zero in the sum
+                        const float d = row[k * S + kw];
+                        mx[k] = fmaxf(mx[k], d);
+                        mn[k] = fminf(mn[k], d);
+                        acc[k] = acc[k] + d;
+                    }
+                }
+            }
+        }
+        if (kh == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) centre[k] = row[k * S + 2];
+        }
+    }
+    if (j >= Hs) return;
+    uint32_t packed = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // A NaN tap makes the sum NaN (torch's max pool propagates it too): the ratio is NaN and the test fails.  Opposite
+        // infinities also give a NaN sum, and fail the test as well (ratio = inf / NaN).
+        const float mean = acc[k] / 25.0f;
+        const float ratio = (mx[k] - mn[k]) / (mean + 1e-6f);
+        bool ok = (acc[k] == acc[k]) && (ratio < 0.1f) && (centre[k] > 0.0f);
+        if (select != EGOPRIOR_SELECT_ALL && (i + k) < Ws) {
+            if (mask != nullptr) {
+                const uint8_t m = mask[(size_t)v * W + (size_t)(i + k) * S];
+                ok = ok && ((select == EGOPRIOR_SELECT_STATIC) ? (m == 0) : (m != 0));
+            } else if (select == EGOPRIOR_SELECT_DYNAMIC) {
+                ok = false;
+            }
+        }
+        packed |= ok ? (1u << (8 * k)) : 0u;
+    }
+    const size_t o = (size_t)j * Ws + i;
+    if (i + 3 < Ws && (o & 3) == 0) {
+        *reinterpret_cast<uint32_t*>(&flags[o]) = packed;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < Ws) flags[o + k] = (uint8_t)((packed >> (8 * k)) & 1u);
+    }
+}
+
 // window taps straight from global memory (large subsample factors, where windows do not overlap)
 __global__ void __launch_bounds__(256) k_reliable_flags_direct(const float* __restrict__ depth,
                                                                const uint8_t* __restrict__ mask, int H, int W, int s,
@@ -481,7 +605,13 @@ bool carve_compact_ws(void* ws, size_t bytes, int64_t n, CompactWs& c) {
 int launch_flags(const float* d_depth, const uint8_t* d_mask, int H, int W, int s, int select, uint8_t* flags,
                  hipStream_t st) {
     const int Hs = (H + s - 1) / s, Ws = (W + s - 1) / s;
-    if (s <= 4) {
+    if (s == 1) {
+        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags_row4<1>, dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
+                  d_depth, d_mask, H, W, Hs, Ws, select, flags);
+    } else if (s == 2) {
+        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags_row4<2>, dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
+                  d_depth, d_mask, H, W, Hs, Ws, select, flags);
+    } else if (s <= 4) {
         const int fw = (EP_MASK_SX - 1) * s + 5, fh = (EP_MASK_SY - 1) * s + 5;
         const dim3 grid((Ws + EP_MASK_SX - 1) / EP_MASK_SX, (Hs + EP_MASK_SY - 1) / EP_MASK_SY);
         EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,

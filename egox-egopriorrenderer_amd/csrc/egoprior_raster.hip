@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
 // DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
 // the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
-template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = true>
+template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -757,41 +757,56 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 bq[u] = val[u] ? (info.x & 0xFFFFu) + sub : 0u;
             }
         } else {
-            // Level 1: 64 equal-width ranges of [kmin, kmax].
+            // Level 1: NB equal-width ranges of [kmin, kmax].  Their histogram, and then the table that maps a range to
+            // its first bucket and sub-range count, live in the first bytes of S, which is not in use until the scatter.
+            constexpr int LOGR = __builtin_ctz((unsigned)NB);
+            static_assert(8 * NB <= 16 * C, "the level-1 table fits into S");
             const u64 range = kmax - kmin;
             int cshift = 0;
-            if (range >= 64ull) cshift = (64 - __builtin_clzll(range)) - 6;
+            if (range >= (u64)NB) cshift = (64 - __builtin_clzll(range)) - LOGR;
+            uint32_t* const h1 = reinterpret_cast<uint32_t*>(S);
             __syncthreads();  // previous chunk's readers of S / bkt / slots are done
-            bkt[lane] = 0u;   // the first 64 counters take the level-1 histogram, then all are cleared for level 2
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                h1[q * 64 + lane] = 0u;
+                bkt[q * 64 + lane] = 0u;
+            }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
-                if (val[u]) atomicAdd(&bkt[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
+                if (val[u]) atomicAdd(&h1[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
             __syncthreads();
-            uint32_t cinfo;  // lane c: first bucket of range c | log2(sub-ranges) << 16
             {
-                const uint32_t cc = bkt[lane];
-                __syncthreads();
+                uint32_t inf[PER];  // sub-ranges | log2(sub-ranges) << 16 of this lane's PER ranges
+                uint32_t sum = 0;
 #pragma unroll
-                for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
-                int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
-                fl = min(fl, cshift);                                 // cannot cut finer than one key value
-                const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
-                uint32_t incl = nf;
+                for (int q = 0; q < PER; ++q) {
+                    const uint32_t cc = h1[lane * PER + q];
+                    int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
+                    fl = min(fl, cshift);                                 // cannot cut finer than one key value
+                    const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
+                    inf[q] = nf | ((uint32_t)fl << 16);
+                    sum += nf;
+                }
+                uint32_t incl = sum;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint32_t o = __shfl_up(incl, d);
                     if (lane >= d) incl += o;
                 }
-                cinfo = (incl - nf) | ((uint32_t)fl << 16);
+                uint32_t run = incl - sum;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    h1[lane * PER + q] = run | (inf[q] & 0xFFFF0000u);  // first bucket | log2(sub-ranges) << 16
+                    run += inf[q] & 0xFFFFu;
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
-                // the cross-lane read is made by all lanes (records that were filtered out look up range 0)
-                const u64 d = val[u] ? make_key(rec[u].y, rec[u].x) - kmin : 0ull;
+                const u64 d = val[u] ? make_key(rec[u].y, rec[u].x) - kmin : 0ull;  // filtered-out records: range 0
                 const uint32_t c = (uint32_t)(d >> cshift);
-                const uint32_t info = (uint32_t)__shfl((int)cinfo, (int)c);
+                const uint32_t info = h1[c];
                 const int fl = (int)(info >> 16);
                 bq[u] = val[u] ? (info & 0xFFFFu) + (uint32_t)((d - ((u64)c << cshift)) >> (cshift - fl)) : 0u;
             }
@@ -1357,7 +1372,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_SWEEP(256, 256, 4);
             break;
         case 6:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, true>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 7:

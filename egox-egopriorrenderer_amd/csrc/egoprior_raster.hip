@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
     // The bucket counters are dead once a chunk is sorted and the slot lists are dead once it is merged, so the two share
     // storage: with C = NB = 1024 a wave needs exactly 20 KiB and eight waves fit a CU's 160 KiB.
-    constexpr int AUXB = (NB * 4 > EP_K * 64 * 2) ? NB * 4 : EP_K * 64 * 2;
+    constexpr int AUXB = (NB * 4 > (EP_K + 1) * 64 * 2) ? NB * 4 : (EP_K + 1) * 64 * 2;  // K slot rows + a spare one
     __shared__ __align__(16) unsigned char aux[AUXB];
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
     uint16_t(*const slots)[64] = reinterpret_cast<uint16_t(*)[64]>(aux);
@@ -1092,26 +1092,24 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 }
             }
             EP_STAMP(4);
-            // every lane appends its own hits, lowest record first
-            while (__ballot(hm_lo != 0u) != 0ull) {
-                if (hm_lo != 0u) {
-                    const int t = __builtin_ctz(hm_lo);
-                    hm_lo &= hm_lo - 1u;
-                    slots[cnt][lane] = (uint16_t)(j0 + t);
-                    ++cnt;
-                    if (cnt >= K) {
-                        hm_lo = 0u;
-                        hm_hi = 0u;
-                    }
-                }
-            }
-            while (__ballot(hm_hi != 0u) != 0ull) {
-                if (hm_hi != 0u) {
-                    const int t = __builtin_ctz(hm_hi);
-                    hm_hi &= hm_hi - 1u;
-                    slots[cnt][lane] = (uint16_t)(j0 + 32 + t);
-                    ++cnt;
-                    if (cnt >= K) hm_hi = 0u;
+            // Every lane appends its own hits, lowest record first, two per trip: `take` of them fit below K, and a
+            // write that has no hit left to store goes to the spare row past the K real ones.
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t hm = half == 0 ? hm_lo : hm_hi;
+                const int take = min(__popc(hm), K - cnt);  // K - cnt >= 0
+                uint16_t* row = &slots[cnt][lane];
+                uint16_t* const spare = &slots[EP_K][lane];
+                const uint32_t jb = (uint32_t)(j0 + 32 * half);
+                cnt += take;
+                for (int i = 0; __ballot(i < take) != 0ull; i += 2) {
+                    const uint32_t t1 = (uint32_t)__builtin_ctz(hm | 0x80000000u);
+                    hm &= hm - 1u;
+                    const uint32_t t2 = (uint32_t)__builtin_ctz(hm | 0x80000000u);
+                    hm &= hm - 1u;
+                    *((i < take) ? row : spare) = (uint16_t)(jb + t1);
+                    *((i + 1 < take) ? row + 64 : spare) = (uint16_t)(jb + t2);
+                    row += 128;
                 }
             }
             EP_STAMP(5);

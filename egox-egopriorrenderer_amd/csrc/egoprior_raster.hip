@@ -130,7 +130,8 @@ __device__ __forceinline__ int64_t live_count(const int32_t* d_n, int64_t cap) {
     return v < cap ? v : cap;
 }
 
-#define EP_BIN_PPB 2048  // points per workgroup in the LDS-aggregated binning kernels
+#define EP_BIN_PPB 2048  // points per workgroup in the binning kernels (256 threads)
+#define EP_BIN_PPT 8  // ... per thread
 
 // world cloud [a | b] -> NDC records (+ per-tile counts when do_count).  PROJECT=false: `a` already holds NDC
 // records (b unused) and nothing is written to `out`.  LDS_AGG: the workgroup first counts into an LDS histogram of
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
     const int64_t nb = (b != nullptr) ? live_count(d_n_b, cap_b) : 0;
     const int64_t n = na + nb;
     if (blockIdx.x == 0 && threadIdx.x == 0 && d_total != nullptr) *d_total = (int32_t)n;
+    if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;  // the grid is sized for the capacity; the live count is smaller
     if (LDS_AGG && do_count) {
         for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
         __syncthreads();
@@ -292,27 +294,39 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
     const int64_t n = live_count(d_n, cap);
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
-        const int64_t lim = (base + EP_BIN_PPB < n_round) ? base + EP_BIN_PPB : n_round;
         if (LDS_AGG) {
             __syncthreads();
             for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
             __syncthreads();
         }
+        // a thread's EP_BIN_PPT records are fetched together and stay in registers for both passes
+        egoprior_point pin[EP_BIN_PPT];
+#pragma unroll
+        for (int k = 0; k < EP_BIN_PPT; ++k) {
+            int64_t i = base + k * 256 + threadIdx.x;
+            i = i < n ? i : n - 1;
+            pin[k] = ndc[i];
+        }
+        uint32_t rx[EP_BIN_PPT], ry[EP_BIN_PPT];  // tile rectangle: first | last << 16 per axis; rx all ones: not binned
+#pragma unroll
+        for (int k = 0; k < EP_BIN_PPT; ++k) {
+            const int64_t i = base + k * 256 + threadIdx.x;
+            int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+            const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
+            rx[k] = hit ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
+            ry[k] = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
+        }
         for (int pass = LDS_AGG ? 0 : 1; pass < 2; ++pass) {
-            for (int64_t i = base + threadIdx.x; i < lim; i += blockDim.x) {
-                const bool live = i < n;
-                float ox = 0.f, oy = 0.f, oz = -1.f;
-                if (live) {
-                    const egoprior_point p = ndc[i];
-                    ox = p.x;
-                    oy = p.y;
-                    oz = p.z;
-                }
-                int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-                const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
+#pragma unroll
+            for (int k = 0; k < EP_BIN_PPT; ++k) {
+                const int64_t i = base + k * 256 + threadIdx.x;
+                const bool hit = rx[k] != 0xFFFFFFFFu;
+                const int tx0 = (int)(rx[k] & 0xFFFFu), tx1 = (int)(rx[k] >> 16);
+                const int ty0 = (int)(ry[k] & 0xFFFFu), ty1 = (int)(ry[k] >> 16);
                 // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order), NDC x, y
+                const float oz = pin[k].z;
                 const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
-                                               __float_as_uint(ox), __float_as_uint(oy));
+                                               __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
                 if (!LDS_AGG)
                     bin_point<1>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
                 else if (pass == 0)
@@ -1097,7 +1111,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 uint32_t hm = half == 0 ? hm_lo : hm_hi;
-                const int take = min(__popc(hm), K - cnt);  // K - cnt >= 0
+                const int take = min((int)__popc(hm), (int)(K - cnt));  // K - cnt >= 0
                 uint16_t* row = &slots[cnt][lane];
                 uint16_t* const spare = &slots[EP_K][lane];
                 const uint32_t jb = (uint32_t)(j0 + 32 * half);
@@ -1287,7 +1301,8 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
 }
 
 // LDS-aggregated binning needs one 32-bit counter per tile in LDS
-bool lds_agg_ok(int n_tiles) { return (size_t)n_tiles * sizeof(uint32_t) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
+size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)n_tiles; }
+bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
 
 int bin_grid(int64_t n) {
     int64_t b = (n + EP_BIN_PPB - 1) / EP_BIN_PPB;
@@ -1343,7 +1358,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
     if (lds_agg_ok(n_tiles))
-        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), sizeof(uint32_t) * n_tiles, s, g,
+        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
                   d_ndc, n, d_n, w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
     else
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill<false>, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n,
@@ -1466,7 +1481,7 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     egoprior_camera cam_unused = {};
     if (lds_agg_ok(n_tiles))
         EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256),
-                  sizeof(uint32_t) * n_tiles, s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
+                  bin_lds_bytes(n_tiles), s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
                   (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1);
     else
         EP_LAUNCH("k_project_count", (ep::k_project_count<false, false>), dim3(bin_grid(n)), dim3(256), 0, s,
@@ -1507,7 +1522,7 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     if (lds_agg_ok(n_tiles))
         EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256),
-                  sizeof(uint32_t) * n_tiles, s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
+                  bin_lds_bytes(n_tiles), s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
                   w.total, w.tile_count, 1);
     else
         EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n)), dim3(256), 0, s, *cam, g,

@@ -105,20 +105,64 @@ __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, 
 
 // LDS flavour of the same walk: LDS atomics resolve same-address lanes in hardware, so every lane simply bumps the
 // counter of each tile of its rectangle.  FILL: counters hold absolute next-slot numbers and the entry is written.
+// Neighbouring lanes hold neighbouring points of an exo frame, and those mostly cover the same tiles: lanes are
+// grouped into runs of consecutive lanes with identical tile rectangles, and only the first lane of a run touches the
+// counters, adding the run's length (FILL: it then hands the slots it got to the lanes of its run).  Must be called by
+// whole waves; lanes without a point pass live = false.
 template <bool FILL>
 __device__ __forceinline__ void bin_point_lds(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                               uint32_t* hist, uint4* __restrict__ list, uint32_t capacity,
                                               uint4 entry) {
+    const int lane = lane_id();
+    const uint32_t rx = live ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
+    const uint32_t ry = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
+    const uint32_t prx = (uint32_t)__shfl_up((int)rx, 1), pry = (uint32_t)__shfl_up((int)ry, 1);
+    const bool head = live && (lane == 0 || rx != prx || ry != pry);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long stops = heads | __ballot(!live);  // a run ends before the next head or empty lane
+    const unsigned long long above = (lane == 63) ? 0ull : (stops >> (lane + 1));
+    const uint32_t runlen = (above != 0ull) ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
     if (!live) return;
+    const int head_lane = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));  // lane's own run head (exists: live)
     for (int ty = ty0; ty <= ty1; ++ty) {
         for (int tx = tx0; tx <= tx1; ++tx) {
             const int t = ty * tiles_x + tx;
             if (FILL) {
-                const uint32_t slot = atomicAdd(&hist[t], 1u);
+                uint32_t slot0 = 0u;
+                if (head) slot0 = atomicAdd(&hist[t], runlen);
+                // all lanes of a run walk the same rectangle, so the head is in this iteration too
+                const uint32_t slot = (uint32_t)__shfl((int)slot0, head_lane) + (uint32_t)(lane - head_lane);
                 if (slot < capacity) list[slot] = entry;
             } else {
-                atomicAdd(&hist[t], 1u);
+                if (head) atomicAdd(&hist[t], runlen);
             }
+        }
+    }
+}
+
+// The same run grouping straight on the global cursors (no LDS stage): one returning global atomic per run and tile.
+__device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                                      uint32_t* __restrict__ cursor,
+                                                      const uint32_t* __restrict__ tile_start, uint4* __restrict__ list,
+                                                      uint32_t capacity, uint4 entry) {
+    const int lane = lane_id();
+    const uint32_t rx = live ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
+    const uint32_t ry = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
+    const uint32_t prx = (uint32_t)__shfl_up((int)rx, 1), pry = (uint32_t)__shfl_up((int)ry, 1);
+    const bool head = live && (lane == 0 || rx != prx || ry != pry);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long stops = heads | __ballot(!live);
+    const unsigned long long above = (lane == 63) ? 0ull : (stops >> (lane + 1));
+    const uint32_t runlen = (above != 0ull) ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
+    if (!live) return;
+    const int head_lane = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
+    for (int ty = ty0; ty <= ty1; ++ty) {
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int t = ty * tiles_x + tx;
+            uint32_t slot0 = 0u;
+            if (head) slot0 = tile_start[t] + atomicAdd(&cursor[t], runlen);
+            const uint32_t slot = (uint32_t)__shfl((int)slot0, head_lane) + (uint32_t)(lane - head_lane);
+            if (slot < capacity) list[slot] = entry;
         }
     }
 }
@@ -328,7 +372,8 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
                 const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
                                                __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
                 if (!LDS_AGG)
-                    bin_point<1>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
+                    bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity,
+                                          entry);
                 else if (pass == 0)
                     bin_point_lds<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, 0u, entry);
                 else
@@ -1302,7 +1347,9 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
 
 // LDS-aggregated binning needs one 32-bit counter per tile in LDS
 size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)n_tiles; }
-bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
+// option "bin_lds": bit 0 = the counting pass aggregates per workgroup in LDS, bit 1 = the fill pass does as well
+bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && (ep_host::option("bin_lds") & 1) != 0; }
+bool lds_fill_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && (ep_host::option("bin_lds") & 2) != 0; }
 
 int bin_grid(int64_t n) {
     int64_t b = (n + EP_BIN_PPB - 1) / EP_BIN_PPB;
@@ -1357,7 +1404,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
-    if (lds_agg_ok(n_tiles))
+    if (lds_fill_ok(n_tiles))
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
                   d_ndc, n, d_n, w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
     else

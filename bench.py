@@ -241,7 +241,15 @@ def main():
         tr = ROOT / "profiles" / "pmc_traffic.json"
         if tr.exists():
             try:
-                roofline["traffic"] = json.load(open(tr)).get(dominant)
+                pmc = json.load(open(tr))
+                roofline["traffic"] = pmc.get(dominant)
+                # the bound that actually applies to this kernel: VALU issue.  A wave64 VALU instruction occupies its
+                # SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.
+                insts = pmc.get("_sq_per_launch", {}).get(dominant, {}).get("SQ_INSTS_VALU")
+                if insts:
+                    roofline["valu"] = {"wave_insts_per_launch": insts,
+                                        "busy_frac": round(insts * 4 / (1024 * 2.4e9 * k["avg_us"] * 1e-6), 3),
+                                        "source": "profiles/pmc_traffic.json (_sq_per_launch), avg_us measured here"}
             except Exception:
                 pass
 

@@ -1421,8 +1421,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         case 2:  // tiny chunks: forces the multi-chunk path on small inputs (tests)
             EP_SWEEP(64, 64, 2);
             break;
-        case 3:
-            EP_SWEEP(512, 512, 3);
+        case 3:  // larger chunks: faster for a frame on its own, slower with several frames in flight
+            EP_SWEEP(1024, 1024, 2);
             break;
         case 4:
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 40>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
@@ -1431,12 +1431,18 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         case 5:
             EP_SWEEP(256, 256, 4);
             break;
+        case 8:
+            EP_SWEEP(512, 512, 4);
+            break;
+        case 9:
+            EP_SWEEP(256, 256, 3);
+            break;
         case 6:
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, true>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 7:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 64>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 32>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 10:
@@ -1467,8 +1473,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
-        default:
-            EP_SWEEP(1024, 1024, 2);
+        default:  // 512-record chunks: 151 VGPRs and 10.6 KiB of LDS per wave, three waves per SIMD
+            EP_SWEEP(512, 512, 3);
     }
 #undef EP_SWEEP
     return ep_host::check_launch("rasterize");

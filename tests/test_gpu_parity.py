@@ -154,10 +154,11 @@ def test_project_points(engine, size):
     assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["sweep1024", "bubble", "sweep64", "sweep512"])
+@pytest.fixture(params=[0, 1, 2, 3, 6], ids=["sweep512", "bubble", "sweep64", "sweep1024", "sweep1024-sampled"])
 def splat_variant(request):
-    """Every splat kernel variant must give the same bits: the default sweep kernel, the plain register-insertion
-    kernel, and the sweep kernel with 64- and 512-record chunks (64 forces its multi-chunk merge on these small inputs)."""
+    """Every splat kernel variant must give the same bits: the default sweep kernel (512-record chunks), the plain
+    register-insertion kernel, the sweep kernel with 64-record chunks (forces its multi-chunk merge on these small
+    inputs), with 1024-record chunks, and with sampled instead of equal-width level-1 bucket boundaries."""
     from egoprior import _lib
     _lib.set_option("splat_variant", request.param)
     yield request.param

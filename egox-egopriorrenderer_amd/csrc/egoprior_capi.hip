@@ -82,7 +82,7 @@ struct Opt {
 Opt g_opts[] = {
     {"splat_variant", 0},  // 0: sweep, 1024-record chunks; 1: register insertion only; 2: sweep, 64-record chunks;
                            // 3: sweep, 512-record chunks
-    {"bin_lds", 1},        // bit 0: tile counts, bit 1: slot reservations aggregated per workgroup in LDS
+    {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
 };
 }  // namespace
 

@@ -4,7 +4,7 @@
 //   k_project_count : world point -> view -> NDC (pinhole or fisheye), conservative tile rectangle, wave-aggregated
 //                     per-tile counts                                        [HBM-bound: 16 B in, 16 B out per point]
 //   k_tile_scan     : exclusive scan of the tile counts (one workgroup)
-//   k_tile_fill     : same rectangle, wave-aggregated slot reservation, writes point indices into the tile lists
+//   k_tile_fill     : same rectangle, slots reserved per run of lanes, writes the 16-byte tile-list entries
 //   k_splat_sweep   : one wave per 8x8 tile, one lane per pixel; buckets the tile's points by key in LDS, sweeps them
 //                     front to back keeping each pixel's K smallest (depth-bits, index) keys, then composites and
 //                     writes the uint8 frame (and, on request, pytorch3d's idx / zbuf / dists)
@@ -103,39 +103,39 @@ __device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, 
     }
 }
 
-// LDS flavour of the same walk: LDS atomics resolve same-address lanes in hardware, so every lane simply bumps the
-// counter of each tile of its rectangle.  FILL: counters hold absolute next-slot numbers and the entry is written.
-// Neighbouring lanes hold neighbouring points of an exo frame, and those mostly cover the same tiles: lanes are
-// grouped into runs of consecutive lanes with identical tile rectangles, and only the first lane of a run touches the
-// counters, adding the run's length (FILL: it then hands the slots it got to the lanes of its run).  Must be called by
-// whole waves; lanes without a point pass live = false.
-template <bool FILL>
-__device__ __forceinline__ void bin_point_lds(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                              uint32_t* hist, uint4* __restrict__ list, uint32_t capacity,
-                                              uint4 entry) {
+// Run grouping.  Neighbouring lanes hold neighbouring points of an exo frame, and those mostly cover the same tiles:
+// lanes are grouped into runs of consecutive lanes with identical tile rectangles, and only the first lane of a run
+// touches the counters, adding the run's length.  Without it the same-address atomics of a wave serialise.  Must be
+// called by whole waves; lanes without a point pass live = false.
+struct LaneRun {
+    bool head;         // first lane of its run
+    uint32_t len;      // run length (valid on the head)
+    int head_lane;     // lane's run head (valid on live lanes)
+};
+__device__ __forceinline__ LaneRun lane_runs(bool live, int tx0, int tx1, int ty0, int ty1) {
     const int lane = lane_id();
     const uint32_t rx = live ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
     const uint32_t ry = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
     const uint32_t prx = (uint32_t)__shfl_up((int)rx, 1), pry = (uint32_t)__shfl_up((int)ry, 1);
-    const bool head = live && (lane == 0 || rx != prx || ry != pry);
-    const unsigned long long heads = __ballot(head);
+    LaneRun r;
+    r.head = live && (lane == 0 || rx != prx || ry != pry);
+    const unsigned long long heads = __ballot(r.head);
     const unsigned long long stops = heads | __ballot(!live);  // a run ends before the next head or empty lane
     const unsigned long long above = (lane == 63) ? 0ull : (stops >> (lane + 1));
-    const uint32_t runlen = (above != 0ull) ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
-    if (!live) return;
-    const int head_lane = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));  // lane's own run head (exists: live)
+    r.len = (above != 0ull) ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
+    r.head_lane = live ? 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull)) : lane;
+    return r;
+}
+
+// Counting into a workgroup's LDS histogram: two 16-bit counters per word (a workgroup adds at most EP_BIN_PPB to a tile).
+__device__ __forceinline__ void count_point_lds(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                                uint32_t* hist) {
+    const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
+    if (!r.head) return;
     for (int ty = ty0; ty <= ty1; ++ty) {
         for (int tx = tx0; tx <= tx1; ++tx) {
             const int t = ty * tiles_x + tx;
-            if (FILL) {
-                uint32_t slot0 = 0u;
-                if (head) slot0 = atomicAdd(&hist[t], runlen);
-                // all lanes of a run walk the same rectangle, so the head is in this iteration too
-                const uint32_t slot = (uint32_t)__shfl((int)slot0, head_lane) + (uint32_t)(lane - head_lane);
-                if (slot < capacity) list[slot] = entry;
-            } else {
-                if (head) atomicAdd(&hist[t], runlen);
-            }
+            atomicAdd(&hist[t >> 1], r.len << ((t & 1) * 16));
         }
     }
 }
@@ -146,22 +146,15 @@ __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx
                                                       const uint32_t* __restrict__ tile_start, uint4* __restrict__ list,
                                                       uint32_t capacity, uint4 entry) {
     const int lane = lane_id();
-    const uint32_t rx = live ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
-    const uint32_t ry = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
-    const uint32_t prx = (uint32_t)__shfl_up((int)rx, 1), pry = (uint32_t)__shfl_up((int)ry, 1);
-    const bool head = live && (lane == 0 || rx != prx || ry != pry);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long stops = heads | __ballot(!live);
-    const unsigned long long above = (lane == 63) ? 0ull : (stops >> (lane + 1));
-    const uint32_t runlen = (above != 0ull) ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
+    const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
     if (!live) return;
-    const int head_lane = 63 - __builtin_clzll(heads & ((2ull << lane) - 1ull));
     for (int ty = ty0; ty <= ty1; ++ty) {
         for (int tx = tx0; tx <= tx1; ++tx) {
             const int t = ty * tiles_x + tx;
             uint32_t slot0 = 0u;
-            if (head) slot0 = tile_start[t] + atomicAdd(&cursor[t], runlen);
-            const uint32_t slot = (uint32_t)__shfl((int)slot0, head_lane) + (uint32_t)(lane - head_lane);
+            if (r.head) slot0 = tile_start[t] + atomicAdd(&cursor[t], r.len);
+            // all lanes of a run walk the same rectangle, so the head is in this iteration too
+            const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
             if (slot < capacity) list[slot] = entry;
         }
     }
@@ -196,8 +189,9 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
     const int64_t n = na + nb;
     if (blockIdx.x == 0 && threadIdx.x == 0 && d_total != nullptr) *d_total = (int32_t)n;
     if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;  // the grid is sized for the capacity; the live count is smaller
+    const int n_words = (n_tiles + 1) >> 1;
     if (LDS_AGG && do_count) {
-        for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
+        for (int t = threadIdx.x; t < n_words; t += blockDim.x) hist[t] = 0u;
         __syncthreads();
     }
     // whole waves stay in the loops together (the binning uses wave-wide ballots)
@@ -227,8 +221,7 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
                 const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
                 if (LDS_AGG)
-                    bin_point_lds<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, 0u,
-                                         make_uint4(0u, 0u, 0u, 0u));
+                    count_point_lds(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist);
                 else
                     bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count, nullptr, nullptr, 0u,
                                  make_uint4(0u, 0u, 0u, 0u));
@@ -237,9 +230,10 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
     }
     if (LDS_AGG && do_count) {
         __syncthreads();
-        for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-            const uint32_t c = hist[t];
-            if (c != 0u) atomicAdd(&tile_count[t], c);
+        for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+            const uint32_t c = hist[w];
+            if ((c & 0xFFFFu) != 0u) atomicAdd(&tile_count[2 * w], c & 0xFFFFu);
+            if ((c >> 16) != 0u) atomicAdd(&tile_count[2 * w + 1], c >> 16);
         }
     }
 }
@@ -324,26 +318,17 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     }
 }
 
-// Second binning pass: writes point indices into the tile lists.  LDS_AGG: each workgroup takes EP_BIN_PPB
-// consecutive points, counts them per tile in LDS, reserves one contiguous range per touched tile with a single
-// global atomic, then hands out the slots of that range from LDS.
-template <bool LDS_AGG>
+// Second binning pass: writes the tile lists.  Every thread fetches its EP_BIN_PPT records together; the first lane of
+// a run (see lane_runs) reserves the run's slots in each tile of the rectangle with one returning global atomic and
+// hands them to its lanes, so the 16-byte entries of a run land in consecutive slots.
 __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_point* __restrict__ ndc, int64_t cap,
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
                                                    uint32_t* __restrict__ tile_cursor, uint4* __restrict__ list,
                                                    uint32_t capacity) {
-    extern __shared__ uint32_t hist[];
-    const int n_tiles = g.tiles_x * g.tiles_y;
     const int64_t n = live_count(d_n, cap);
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
-        if (LDS_AGG) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) hist[t] = 0u;
-            __syncthreads();
-        }
-        // a thread's EP_BIN_PPT records are fetched together and stay in registers for both passes
         egoprior_point pin[EP_BIN_PPT];
 #pragma unroll
         for (int k = 0; k < EP_BIN_PPT; ++k) {
@@ -351,42 +336,16 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
             i = i < n ? i : n - 1;
             pin[k] = ndc[i];
         }
-        uint32_t rx[EP_BIN_PPT], ry[EP_BIN_PPT];  // tile rectangle: first | last << 16 per axis; rx all ones: not binned
 #pragma unroll
         for (int k = 0; k < EP_BIN_PPT; ++k) {
             const int64_t i = base + k * 256 + threadIdx.x;
             int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
             const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
-            rx[k] = hit ? ((uint32_t)tx0 | ((uint32_t)tx1 << 16)) : 0xFFFFFFFFu;
-            ry[k] = (uint32_t)ty0 | ((uint32_t)ty1 << 16);
-        }
-        for (int pass = LDS_AGG ? 0 : 1; pass < 2; ++pass) {
-#pragma unroll
-            for (int k = 0; k < EP_BIN_PPT; ++k) {
-                const int64_t i = base + k * 256 + threadIdx.x;
-                const bool hit = rx[k] != 0xFFFFFFFFu;
-                const int tx0 = (int)(rx[k] & 0xFFFFu), tx1 = (int)(rx[k] >> 16);
-                const int ty0 = (int)(ry[k] & 0xFFFFu), ty1 = (int)(ry[k] >> 16);
-                // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order), NDC x, y
-                const float oz = pin[k].z;
-                const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
-                                               __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
-                if (!LDS_AGG)
-                    bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity,
-                                          entry);
-                else if (pass == 0)
-                    bin_point_lds<false>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, nullptr, 0u, entry);
-                else
-                    bin_point_lds<true>(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist, list, capacity, entry);
-            }
-            if (LDS_AGG && pass == 0) {
-                __syncthreads();
-                for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-                    const uint32_t c = hist[t];
-                    if (c != 0u) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
-                }
-                __syncthreads();
-            }
+            // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order), NDC x, y
+            const float oz = pin[k].z;
+            const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
+                                           __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
+            bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
         }
     }
 }
@@ -431,6 +390,7 @@ __device__ unsigned long long g_stamps[16];
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
+__device__ uint32_t g_chunk_stats[8];
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -744,6 +704,16 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if (cs == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
             continue;
         }
+#ifdef EP_TILE_TIMES
+        if (lane == 0) {
+            atomicAdd(&g_chunk_stats[0], 1u);                          // chunks loaded
+            atomicAdd(&g_chunk_stats[1], (uint32_t)(chunk_no > 0));    // ... after the first
+            atomicAdd(&g_chunk_stats[2], (uint32_t)(chunk_no > 0 && T == ~0ull));  // ... of those, unfiltered
+            atomicAdd(&g_chunk_stats[3], (uint32_t)m);                 // records kept
+            atomicAdd(&g_chunk_stats[4], (uint32_t)(chunk_no > 0 ? m : 0));
+            atomicAdd(&g_chunk_stats[5], (uint32_t)((chunk_no > 0 && T == ~0ull) ? m : 0));
+        }
+#endif
         if (m == 0) continue;
         EP_STAMP(1);
         kmin = wave_min_u64(kmin);
@@ -1346,10 +1316,10 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
 }
 
 // LDS-aggregated binning needs one 32-bit counter per tile in LDS
-size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)n_tiles; }
-// option "bin_lds": bit 0 = the counting pass aggregates per workgroup in LDS, bit 1 = the fill pass does as well
-bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && (ep_host::option("bin_lds") & 1) != 0; }
-bool lds_fill_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && (ep_host::option("bin_lds") & 2) != 0; }
+// the counting pass aggregates per workgroup in LDS (two 16-bit counters per word) unless option "bin_lds" is 0
+size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)((n_tiles + 1) >> 1); }
+bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
+static_assert(EP_BIN_PPB < 65536, "a workgroup's per-tile count must fit into 16 bits");
 
 int bin_grid(int64_t n) {
     int64_t b = (n + EP_BIN_PPB - 1) / EP_BIN_PPB;
@@ -1404,12 +1374,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
-    if (lds_fill_ok(n_tiles))
-        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<true>, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
-                  d_ndc, n, d_n, w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
-    else
-        EP_LAUNCH("k_tile_fill", ep::k_tile_fill<false>, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n,
-                  w.tile_start, w.tile_cursor, w.list, (uint32_t)w.capacity);
+    EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
+              w.tile_cursor, w.list, (uint32_t)w.capacity);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
     EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
               w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
@@ -1446,31 +1412,31 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 10:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 1>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 1>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 11:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 2>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 2>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 12:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 3>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 3>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 14:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 5>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 5>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 15:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 6>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 6>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 16:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 7>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 7>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 13:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         default:  // 512-record chunks: 151 VGPRs and 10.6 KiB of LDS per wave, three waves per SIMD
@@ -1585,6 +1551,14 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
 }
 
 #ifdef EP_TILE_TIMES
+extern "C" int egoprior_debug_chunk_stats(uint32_t* host8, int reset) {
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_chunk_stats), 8 * sizeof(uint32_t)) != hipSuccess) return -3;
+    if (reset) {
+        uint32_t z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_chunk_stats), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
 extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_tile_times), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
 }

@@ -165,7 +165,7 @@ def splat_variant(request):
     _lib.set_option("splat_variant", 0)
 
 
-@pytest.fixture(params=[1, 0, 3], ids=["count-lds", "all-global", "all-lds"])
+@pytest.fixture(params=[1, 0], ids=["count-lds", "count-global"])
 def bin_variant(request):
     from egoprior import _lib
     _lib.set_option("bin_lds", request.param)

@@ -30,8 +30,14 @@ cam = eng.pinhole_camera(R, t, synth.ego_pinhole_K(He, We), He, We)
 rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
+cs = C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_chunk_stats
+cbuf = (C.c_uint32 * 8)()
+cs(cbuf, 1)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
+cs(cbuf, 0)
+c = list(cbuf)
+print(f"chunks {c[0]} (records kept {c[3]}); later chunks {c[1]} (kept {c[4]}), of those unfiltered {c[2]} (kept {c[5]})")
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()
 assert dbg(buf, 4 * n_tiles) == 0

@@ -61,48 +61,8 @@ __device__ __forceinline__ void project_point(const egoprior_camera& c, float x,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// wave-aggregated per-tile counting / slot reservation
+// per-tile counting / slot reservation
 // ------------------------------------------------------------------------------------------------------------------
-// Every lane walks its own tile rectangle; step k of all lanes is handled together: lanes that name the same tile
-// are found with ballots and one lane issues a single atomic for the group.
-//   MODE 0: counters[t] += group size
-//   MODE 1: slot = tile_start[t] + (counters[t] += group size)   (counters = per-tile cursors in global memory)
-//   MODE 2: slot = (counters[t] += group size)                   (counters = absolute next-slot words, e.g. in LDS)
-template <int MODE>
-__device__ __forceinline__ void bin_point(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                          uint32_t* counters, const uint32_t* __restrict__ tile_start,
-                                          uint4* __restrict__ list, uint32_t capacity, uint4 entry) {
-    const int w = live ? (tx1 - tx0 + 1) : 0;
-    const int ntiles = live ? w * (ty1 - ty0 + 1) : 0;
-    const int lane = lane_id();
-    for (int k = 0;; ++k) {
-        const bool active = k < ntiles;
-        unsigned long long todo = __ballot(active);
-        if (todo == 0ull) break;
-        int t = -1;
-        if (active) {
-            const int dy = k / w;
-            const int dx = k - dy * w;
-            t = (ty0 + dy) * tiles_x + (tx0 + dx);
-        }
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const int tl = __builtin_amdgcn_readlane(t, leader);
-            const unsigned long long same = __ballot(active && t == tl);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&counters[tl], (uint32_t)__popcll(same));
-            if (MODE != 0) {
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                if (active && t == tl) {
-                    const uint32_t slot = (MODE == 1 ? tile_start[tl] : 0u) + base + (uint32_t)lanes_below(same);
-                    if (slot < capacity) list[slot] = entry;
-                }
-            }
-            todo &= ~same;
-        }
-    }
-}
-
 // Run grouping.  Neighbouring lanes hold neighbouring points of an exo frame, and those mostly cover the same tiles:
 // lanes are grouped into runs of consecutive lanes with identical tile rectangles, and only the first lane of a run
 // touches the counters, adding the run's length.  Without it the same-address atomics of a wave serialise.  Must be
@@ -138,6 +98,15 @@ __device__ __forceinline__ void count_point_lds(bool live, int tx0, int tx1, int
             atomicAdd(&hist[t >> 1], r.len << ((t & 1) * 16));
         }
     }
+}
+
+// Counting straight into the global per-tile counters: one atomic per run and tile.
+__device__ __forceinline__ void count_point_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                                   uint32_t* __restrict__ tile_count) {
+    const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
+    if (!r.head) return;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], r.len);
 }
 
 // The same run grouping straight on the global cursors (no LDS stage): one returning global atomic per run and tile.
@@ -223,8 +192,7 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                 if (LDS_AGG)
                     count_point_lds(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist);
                 else
-                    bin_point<0>(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count, nullptr, nullptr, 0u,
-                                 make_uint4(0u, 0u, 0u, 0u));
+                    count_point_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count);
             }
         }
     }

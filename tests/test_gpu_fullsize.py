@@ -1,0 +1,130 @@
+"""Full-size checks on the bench workload (1080p exo, ~2.1 M points, 480x832 ego, K = 20), where the CPU oracle would
+take a minute per frame.  Instead of the oracle, these use properties that do not depend on the size:
+
+* every splat kernel variant (independent implementations of the same selection) returns identical bits;
+* fragments are ordered by (z, index) per pixel, every returned point really covers its pixel, and `dists` / `zbuf`
+  are the point's own values;
+* for a sample of pixels, a brute-force search over ALL points in plain torch float32 (separate mul / add kernels, so
+  no fused multiply-add) finds exactly the same K indices in the same order;
+* rendering twice gives the same bits (the tile lists are filled with atomics in a different order every time).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H, W, He, We = 1080, 1920, 480, 832
+K = 20
+
+
+@pytest.fixture(scope="module")
+def scene(engine):
+    from egoprior import _lib, synth
+    from egoprior import engine as eng
+    dev = engine.device
+    d, rgb, m = synth.make_frames(H, W, [40], 300, device=dev)
+    exo = synth.exo_w2c()
+    T = np.linalg.inv(exo)
+    intr, c2w = synth.exo_intrinsics(H, W), np.eye(4, dtype=np.float32)
+    bg = engine.unproject_frame(d[0], rgb[0], m[0], intr, c2w, T, subsample=1, select=_lib.SELECT_STATIC)
+    dyn = engine.unproject_frame(d[0], rgb[0], m[0], intr, c2w, T, subsample=1, select=_lib.SELECT_DYNAMIC)
+    R, t = eng.split_w2c(synth.ego_orbit_w2c(300, exo)[40])
+    cam = eng.pinhole_camera(R, t, synth.ego_pinhole_K(He, We), He, We)
+    n = bg.n() + dyn.n()
+    ndc = engine.project_points(cam, bg, dyn)[:n].clone()
+    assert n > 1_500_000
+    return dict(bg=bg, dyn=dyn, cam=cam, ndc=ndc, n=n)
+
+
+def _render(engine, scene, ps, variant):
+    from egoprior import _lib
+    from egoprior import engine as eng
+    rp = eng.make_raster_params(ps, He, We, K=K, rotate_cw=True, colors_gt1=-1)
+    _lib.set_option("splat_variant", variant)
+    try:
+        res = engine.render_frame(scene["cam"], rp, scene["bg"], scene["dyn"], want_f32=True, want_fragments=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("splat_variant", 0)
+    assert res["status"].item() == 0
+    return res, rp
+
+
+@pytest.mark.parametrize("ps", [5.0, 1.0])
+def test_variants_agree_and_fragments_are_consistent(engine, scene, ps):
+    ref, rp = _render(engine, scene, ps, 0)
+    for variant in (1, 3, 0):  # plain insertion kernel, 1024-record chunks, and the default once more
+        res, _ = _render(engine, scene, ps, variant)
+        for key in ("idx", "zbuf", "dists", "image_f32", "image"):
+            assert torch.equal(res[key], ref[key]), f"variant {variant}: {key} differs"
+    idx, zb, ds = ref["idx"].long(), ref["zbuf"], ref["dists"]
+    valid = idx >= 0
+    assert valid.any() and (~valid).any()
+    # filled slots form a prefix; unfilled slots hold -1 everywhere
+    assert torch.equal(valid[..., 1:] & ~valid[..., :-1], torch.zeros_like(valid[..., 1:]))
+    assert (zb[~valid] == -1).all() and (ds[~valid] == -1).all()
+    ndc = scene["ndc"]
+    z_of = ndc[:, 2][idx.clamp(min=0)]
+    assert torch.equal(z_of[valid], zb[valid])
+    # order: (z, index) strictly increasing along K
+    both = valid[..., 1:] & valid[..., :-1]
+    dz = zb[..., 1:] - zb[..., :-1]
+    di = idx[..., 1:] - idx[..., :-1]
+    assert ((dz > 0) | ((dz == 0) & (di > 0)))[both].all()
+    # every returned point covers its pixel, and dists is its own squared distance (same float32 operations)
+    xf, yf = O.pixel_ndc_centres(He, We)
+    xf = torch.from_numpy(xf).to(ndc.device)[None, :, None]
+    yf = torch.from_numpy(yf).to(ndc.device)[:, None, None]
+    dx = ndc[:, 0][idx.clamp(min=0)] - xf
+    dy = ndc[:, 1][idx.clamp(min=0)] - yf
+    dx2 = dx * dx
+    dy2 = dy * dy
+    d2 = dx2 + dy2
+    assert torch.equal(d2[valid], ds[valid])
+    r2 = np.float32(rp.radius) * np.float32(rp.radius)
+    assert (ds[valid] < float(r2)).all()
+
+
+@pytest.mark.parametrize("ps", [5.0, 1.0])
+def test_sampled_pixels_against_brute_force(engine, scene, ps):
+    res, rp = _render(engine, scene, ps, 0)
+    ndc = scene["ndc"]
+    dev = ndc.device
+    x, y, z = ndc[:, 0].contiguous(), ndc[:, 1].contiguous(), ndc[:, 2].contiguous()
+    zbits = torch.where(z == 0, torch.zeros_like(z), z).view(torch.int32).long()
+    key_all = (zbits << 32) | torch.arange(ndc.shape[0], device=dev)
+    live = z >= 0  # also false for NaN
+    xf, yf = O.pixel_ndc_centres(He, We)
+    xf, yf = torch.from_numpy(xf).to(dev), torch.from_numpy(yf).to(dev)
+    r2 = float(np.float32(rp.radius) * np.float32(rp.radius))
+    rng = np.random.default_rng(7)
+    pix = [(int(a), int(b)) for a, b in zip(rng.integers(0, He, 300), rng.integers(0, We, 300))]
+    pix += [(yy, xx) for yy in (0, 7, 8, He - 1) for xx in (0, 7, 8, 415, 416, We - 1)]  # tile and image borders
+    big = torch.iinfo(torch.int64).max
+    for c0 in range(0, len(pix), 32):
+        chunk = pix[c0:c0 + 32]
+        py = torch.tensor([p[0] for p in chunk], device=dev)
+        px = torch.tensor([p[1] for p in chunk], device=dev)
+        dx = x[None, :] - xf[px][:, None]
+        dy = y[None, :] - yf[py][:, None]
+        dx2 = dx * dx
+        dy2 = dy * dy
+        d2 = dx2 + dy2
+        hit = (d2 < r2) & live[None, :]
+        keys = torch.where(hit, key_all[None, :], torch.full_like(key_all[None, :], big))
+        best = torch.topk(keys, K, dim=1, largest=False, sorted=True).values
+        want = torch.where(best == big, torch.full_like(best, -1), best & 0xFFFFFFFF).int()
+        got = res["idx"][py, px]
+        assert torch.equal(got, want), f"pixels {chunk}"
+
+
+def test_two_runs_same_bits(engine, scene):
+    a, _ = _render(engine, scene, 5.0, 0)
+    keep = {k: a[k].clone() for k in ("idx", "zbuf", "dists", "image")}
+    for _ in range(3):
+        b, _ = _render(engine, scene, 5.0, 0)
+        for k, v in keep.items():
+            assert torch.equal(b[k], v)

@@ -331,30 +331,6 @@ struct SplatOut {
 
 typedef unsigned long long u64;
 
-// Diagnostic build only (-DEP_STAMPS): per-phase cycle totals of k_splat_sweep, summed over waves.
-#ifdef EP_STAMPS
-__device__ unsigned long long g_stamps[16];
-// cycles are accumulated in registers and added to the global totals once, at the end of the kernel
-#define EP_STAMP_DECL                    \
-    unsigned long long _t0 = clock64(), _t1; \
-    unsigned long long _acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define EP_STAMP(slot)            \
-    do {                          \
-        _t1 = clock64();          \
-        _acc[slot] += _t1 - _t0;  \
-        _t0 = _t1;                \
-    } while (0)
-#define EP_STAMP_FLUSH()                                                  \
-    do {                                                                  \
-        if (threadIdx.x == 0)                                             \
-            for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_stamps[_i], _acc[_i]); \
-    } while (0)
-#else
-#define EP_STAMP_DECL
-#define EP_STAMP(slot)
-#define EP_STAMP_FLUSH()
-#endif
-
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
@@ -623,14 +599,12 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     if (end > capacity) end = capacity;
     if (pos > end) pos = end;
     int chunk_no = 0;
-    EP_STAMP_DECL;
 #ifdef EP_TILE_TIMES
     const unsigned long long tt0 = __builtin_readcyclecounter();
     const uint32_t tt_records = end - pos;
 #endif
 
     while (pos < end) {
-        EP_STAMP(0);
         // ---- load + threshold filter -----------------------------------------------------------------------------
         uint4 rec[RPL];
         bool val[RPL];
@@ -644,7 +618,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         // diagnostic: wait for the records, then fetch them a second time (now cache-resident) and keep both alive
 #pragma unroll
         for (int u = 0; u < RPL; ++u) asm volatile("" ::"v"(rec[u].x));
-        EP_STAMP(8);
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
             const uint32_t e = pos + (uint32_t)(u * 64 + lane);
@@ -683,7 +656,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         }
 #endif
         if (m == 0) continue;
-        EP_STAMP(1);
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
         // Two-level monotone bucket map: 64 level-1 ranges, one per lane; range c, which received cc records, is cut
@@ -854,7 +826,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         // the sweep reads whole blocks of 64: pad the last block with records that never hit and sort last
         for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
             S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
-        EP_STAMP(2);
         if (DBG == 5) {
             const uint4 q = S[lane];
             if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
@@ -880,19 +851,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 big = max(big, be - bs);
             }
         }
-#ifdef EP_STAMPS
-        {
-            int mx = big;
-            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-            if (threadIdx.x == 0) {
-                atomicAdd(&g_stamps[13], (unsigned long long)(mx > EP_RANK_WAVE));
-                atomicAdd(&g_stamps[14], (unsigned long long)mx);
-                atomicAdd(&g_stamps[8], (unsigned long long)(mx > 4));
-                atomicAdd(&g_stamps[9], (unsigned long long)(mx > EP_RANK_SELF));
-                atomicAdd(&g_stamps[15], (unsigned long long)(mx > 32));
-            }
-        }
-#endif
         if (DBG == 6) {
             // timing probe: leave the records in bucket order (wrong output, same downstream work)
         } else if (__ballot(big > (DBG == 7 ? 4096 : EP_RANK_WAVE)) == 0ull) {
@@ -996,7 +954,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
             continue;
         }
-        EP_STAMP(3);
         // ---- sweep front to back ---------------------------------------------------------------------------------
         int cnt = inside ? 0 : K;  // pixels outside the image never take part
         // Later chunks: a pixel whose running list is full only cares about records with a key below its K-th key,
@@ -1024,9 +981,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
         for (int j0 = 0; j0 < m_sweep; j0 += 64) {
-#ifdef EP_STAMPS
-            if (threadIdx.x == 0) atomicAdd(&g_stamps[10], 1ull);
-#endif
             const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
             if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
             // Offer records j0 .. j0+63 to every pixel: each record's (x, y) is read from LDS at a wave-uniform
@@ -1088,7 +1042,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     hm_hi &= (1u << (nb - 32)) - 1u;
                 }
             }
-            EP_STAMP(4);
             // Every lane appends its own hits, lowest record first, two per trip: `take` of them fit below K, and a
             // write that has no hit left to store goes to the spare row past the K real ones.
 #pragma unroll
@@ -1109,16 +1062,8 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     row += 128;
                 }
             }
-            EP_STAMP(5);
         }
         __syncthreads();
-        EP_STAMP(6);
-#ifdef EP_STAMPS
-        if (threadIdx.x == 0) {
-            atomicAdd(&g_stamps[11], (unsigned long long)((m + 63) / 64));
-            atomicAdd(&g_stamps[12], 1ull);
-        }
-#endif
 
         if (DBG == 3) {
             if ((uint32_t)(cnt + slots[0][lane]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
@@ -1193,9 +1138,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
             T = wave_max_u64(mine);
         }
-        EP_STAMP(7);
     }
-    EP_STAMP(8);
     if (DBG != 0 && DBG != 4) return;
     if (DBG == 4) {  // everything but the compositor
         if ((kz[0] ^ ki[19]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
@@ -1210,8 +1153,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;
     }
 #endif
-    EP_STAMP(9);
-    EP_STAMP_FLUSH();
 }
 
 }  // namespace ep
@@ -1532,14 +1473,3 @@ extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
 }
 #endif
 
-#ifdef EP_STAMPS
-extern "C" int egoprior_debug_stamps(unsigned long long* host16, int reset) {
-    if (host16 != nullptr && hipMemcpyFromSymbol(host16, HIP_SYMBOL(ep::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess)
-        return -3;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stamps), z, sizeof(z)) != hipSuccess) return -3;
-    }
-    return 0;
-}
-#endif

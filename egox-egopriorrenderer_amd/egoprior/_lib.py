@@ -91,6 +91,9 @@ def lib():
         if not LIB_PATH.exists():
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {CSRC}` "
                               "(there is no CPU fallback for the ego-prior renderer)")
+        # torch first: the extension must bind to the HIP runtime torch ships and initialises, not to a second copy
+        # (with two runtimes in one process this library's launches do not see torch's device)
+        import torch  # noqa: F401
         L = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -98,6 +98,112 @@ __global__ void __launch_bounds__(256) k_reliable_flags(const float* __restrict_
     flags[(size_t)j * Ws + i] = ok ? 1 : 0;
 }
 
+// Raw hardware max / min.  fmaxf()/fminf() first quiet every operand that might be a signalling NaN (one extra
+// instruction per tap); here a NaN tap makes the 25-tap sum NaN and the test fail whatever max and min return, so the
+// plain instructions do.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// The 5x5 test for four horizontally adjacent samples of one thread, out of an LDS tile with row stride TS whose origin
+// is the top-left tap of the block's first sample.  (tx, ty): the thread's column group and row in the block; (i, v):
+// sample column index of its first sample and image row.  Returns bit k set if sample k is reliable; centre[k] = its depth.
+template <int S, int TS>
+__device__ __forceinline__ uint32_t reliable4(const float* __restrict__ tile, int tx, int ty, int i, int v, int H, int W,
+                                              float (&centre)[4]) {
+    constexpr int RW = 3 * S + 5;     // floats of one window row that the four samples touch
+    constexpr int RV = (RW + 3) / 4;  // ... in 16-byte reads
+    float mx[4], mn[4], acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mx[k] = -INFINITY;
+        mn[k] = INFINITY;
+        acc[k] = 0.0f;
+        centre[k] = 0.0f;
+    }
+    // all four windows inside the image?  (wave-uniform decision: one code path per wave)
+    const bool interior = (v >= 2) && (v + 2 < H) && (i * S >= 2) && ((i + 3) * S + 2 < W);
+    const bool fast = __ballot(!interior) == 0ull;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) {
+        float row[4 * RV];
+        const float4* src = reinterpret_cast<const float4*>(&tile[(ty * S + kh) * TS + 4 * tx * S]);
+#pragma unroll
+        for (int q = 0; q < RV; ++q) {
+            const float4 t = src[q];
+            row[4 * q + 0] = t.x;
+            row[4 * q + 1] = t.y;
+            row[4 * q + 2] = t.z;
+            row[4 * q + 3] = t.w;
+        }
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* r = &row[k * S];
+                mx[k] = max3_raw(max3_raw(mx[k], r[0], r[1]), max3_raw(r[2], r[3], r[4]), r[2]);
+                mn[k] = min3_raw(min3_raw(mn[k], r[0], r[1]), min3_raw(r[2], r[3], r[4]), r[2]);
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) acc[k] = acc[k] + r[kw];
+            }
+        } else {
+            const int yy = v + kh - 2;
+            const bool rowin = (yy >= 0) && (yy < H);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) {
+                    const int xx = (i + k) * S + kw - 2;
+                    if (rowin && xx >= 0 && xx < W) {  // taps outside the image: skipped by max/min, zero in the sum
+                        const float d = row[k * S + kw];
+                        mx[k] = fmaxf(mx[k], d);
+                        mn[k] = fminf(mn[k], d);
+                        acc[k] = acc[k] + d;
+                    }
+                }
+            }
+        }
+        if (kh == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) centre[k] = row[k * S + 2];
+        }
+    }
+    // ratio = (max - min) / (sum / 25 + 1e-6) < 0.1 with two correctly rounded divisions.  Both are first replaced by
+    // reciprocal multiplies (a few 1e-7 of relative error); only a ratio within 1e-5 of the threshold, or a
+    // denominator that lost digits to cancellation, sends the wave to the exact divisions.
+    uint32_t okbits = 0u, unsure = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float mean_a = acc[k] * 0.04f;
+        const float den_a = mean_a + 1e-6f;
+        const float q = (mx[k] - mn[k]) * __builtin_amdgcn_rcpf(den_a);
+        const bool trust = fabsf(den_a) >= 0.125f * fabsf(mean_a);
+        const bool yes = trust && (q < 0.099999f), no = trust && (q > 0.100001f);
+        okbits |= yes ? (1u << k) : 0u;
+        unsure |= (yes || no) ? 0u : (1u << k);  // also every NaN
+    }
+    if (__ballot(unsure != 0u) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mean = acc[k] / 25.0f;
+            const float ratio = (mx[k] - mn[k]) / (mean + 1e-6f);
+            if ((unsure >> k) & 1u) okbits = (okbits & ~(1u << k)) | ((ratio < 0.1f) ? (1u << k) : 0u);
+        }
+    }
+    // A NaN tap makes the sum NaN (torch's max pool propagates it too): the ratio is NaN and the test fails.  Opposite
+    // infinities also give a NaN sum, and fail the test as well (ratio = inf / NaN).
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (!((acc[k] == acc[k]) && (centre[k] > 0.0f))) okbits &= ~(1u << k);
+    return okbits;
+}
+
 // Subsample factors 1 and 2: 64 x 16 samples per block, four horizontally adjacent samples per thread.  A thread pulls
 // each of its five window rows out of the LDS tile once, as 16-byte reads, and feeds all four windows from registers, so a
 // sample costs 2.5 (S=1) or 3.75 (S=2) LDS reads instead of 25.  Same arithmetic, tap by tap, as reliable_at().
@@ -108,9 +214,7 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __rest
     constexpr int BX = 64, BY = 16;
     constexpr int FW = (BX - 1) * S + 5, FH = (BY - 1) * S + 5;
     constexpr int TS = (FW + 3) & ~3;   // row stride in floats, a multiple of 4 so that every thread's reads are aligned
-    constexpr int RW = 3 * S + 5;       // floats of one window row that a thread's four samples touch
-    constexpr int RV = (RW + 3) / 4;    // ... in 16-byte reads
-    static_assert(4 * (BX / 4 - 1) * S + 4 * RV <= TS, "row reads stay inside the tile row");
+    static_assert(4 * (BX / 4 - 1) * S + 4 * ((3 * S + 5 + 3) / 4) <= TS, "row reads stay inside the tile row");
     __shared__ __align__(16) float tile[TS * FH];
     const int i0 = blockIdx.x * BX, j0 = blockIdx.y * BY;
     {
@@ -137,71 +241,13 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __rest
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = i0 + 4 * tx, j = j0 + ty;
     const int v = j * S;  // image row of the samples; sample k sits at image column (i + k) * S
-    float mx[4], mn[4], acc[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        mx[k] = -INFINITY;
-        mn[k] = INFINITY;
-        acc[k] = 0.0f;
-    }
-    float centre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    // all four windows inside the image?  (wave-uniform decision: one code path per wave)
-    const bool interior = (v >= 2) && (v + 2 < H) && (i * S >= 2) && ((i + 3) * S + 2 < W);
-    const bool fast = __ballot(!interior) == 0ull;
-#pragma unroll
-    for (int kh = 0; kh < 5; ++kh) {
-        float row[4 * RV];
-        const float4* src = reinterpret_cast<const float4*>(&tile[(ty * S + kh) * TS + 4 * tx * S]);
-#pragma unroll
-        for (int q = 0; q < RV; ++q) {
-            const float4 t = src[q];
-            row[4 * q + 0] = t.x;
-            row[4 * q + 1] = t.y;
-            row[4 * q + 2] = t.z;
-            row[4 * q + 3] = t.w;
-        }
-        if (fast) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    const float d = row[k * S + kw];
-                    mx[k] = fmaxf(mx[k], d);
-                    mn[k] = fminf(mn[k], d);
-                    acc[k] = acc[k] + d;
-                }
-            }
-        } else {
-            const int yy = v + kh - 2;
-            const bool rowin = (yy >= 0) && (yy < H);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                for (int kw = 0; kw < 5; ++kw) {
-                    const int xx = (i + k) * S + kw - 2;
-                    if (rowin && xx >= 0 && xx < W) {  // taps outside the image: skipped by max/min, zero in the sum
-                        const float d = row[k * S + kw];
-                        mx[k] = fmaxf(mx[k], d);
-                        mn[k] = fminf(mn[k], d);
-                        acc[k] = acc[k] + d;
-                    }
-                }
-            }
-        }
-        if (kh == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) centre[k] = row[k * S + 2];
-        }
-    }
+    float centre[4];
+    const uint32_t okbits = reliable4<S, TS>(tile, tx, ty, i, v, H, W, centre);
     if (j >= Hs) return;
     uint32_t packed = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        // A NaN tap makes the sum NaN (torch's max pool propagates it too): the ratio is NaN and the test fails.  Opposite
-        // infinities also give a NaN sum, and fail the test as well (ratio = inf / NaN).
-        const float mean = acc[k] / 25.0f;
-        const float ratio = (mx[k] - mn[k]) / (mean + 1e-6f);
-        bool ok = (acc[k] == acc[k]) && (ratio < 0.1f) && (centre[k] > 0.0f);
+        bool ok = ((okbits >> k) & 1u) != 0u;
         if (select != EGOPRIOR_SELECT_ALL && (i + k) < Ws) {
             if (mask != nullptr) {
                 const uint8_t m = mask[(size_t)v * W + (size_t)(i + k) * S];
@@ -512,6 +558,134 @@ __global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ s
     }
 }
 
+// Same reduction, 64 x 16 pixels per workgroup and four horizontally adjacent pixels per thread (W % 4 == 0).  The next
+// frame's depth footprint, mask bytes and colour bytes are fetched into registers while the current frame is worked on,
+// so a frame costs its arithmetic and not two exposed memory latencies.  Per pixel the terms are added in the same
+// order as in the one-pixel-per-thread kernel.
+__global__ void __launch_bounds__(256) k_meanbg_accumulate_row4(float* __restrict__ state,
+                                                                const float* __restrict__ depth,
+                                                                const uint8_t* __restrict__ rgb,
+                                                                const uint8_t* __restrict__ mask, int F,
+                                                                long long first_index, int H, int W) {
+    constexpr int BX = 64, BY = 16, FW = BX + 4, FH = BY + 4, TS = FW;  // 68 floats per tile row: a multiple of 4
+    constexpr int NL = (TS * FH + 255) / 256;
+    __shared__ __align__(16) float tile[TS * FH];
+    __shared__ float lut[256];
+    const int x0 = blockIdx.x * BX, y0 = blockIdx.y * BY;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int u = x0 + 4 * tx, v = y0 + ty;  // first of the thread's four pixels
+    const bool inside = (u < W) && (v < H);  // W % 4 == 0: all four or none
+    const size_t HW = (size_t)H * W;
+    const size_t pix = inside ? (size_t)v * W + u : 0;
+    lut[threadIdx.x] = (float)threadIdx.x / 255.0f;  // rgb = u8 / 255.0 (vipe/utils/io.py:250)
+
+    // footprint element e of this thread's q-th load -> clamped image offset (the same for every frame)
+    uint32_t foff[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        const int e = min((int)threadIdx.x + q * 256, TS * FH - 1);
+        const int ly = e / TS, lx = e - ly * TS;
+        int yy = y0 - 2 + ly, xx = x0 - 2 + lx;
+        yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+        foff[q] = (uint32_t)yy * (uint32_t)W + (uint32_t)xx;
+    }
+
+    float acc[4][4][4];  // [pixel][level][quantity]
+    int cnt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[k][l][q] = inside ? state[(size_t)(l * 4 + q) * HW + pix + k] : 0.0f;
+        cnt[k] = inside ? ((const int*)state)[16 * HW + pix + k] : 0;
+    }
+
+    // registers holding the frame that is worked on next
+    float nfoot[NL];
+    uint32_t nmask = 0u, nrgb[3] = {0u, 0u, 0u};
+    auto fetch = [&](int f) {
+        const float* dfr = depth + (size_t)f * HW;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) nfoot[q] = dfr[foff[q]];
+        if (mask != nullptr) nmask = *reinterpret_cast<const uint32_t*>(mask + (size_t)f * HW + pix);
+        const uint32_t* c = reinterpret_cast<const uint32_t*>(rgb + ((size_t)f * HW + pix) * 3);  // 12 bytes, 4-aligned
+        nrgb[0] = c[0];
+        nrgb[1] = c[1];
+        nrgb[2] = c[2];
+    };
+    if (F > 0) fetch(0);
+    for (int f = 0; f < F; ++f) {
+        __syncthreads();  // the previous frame's readers of the tile are done
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int e = (int)threadIdx.x + q * 256;
+            if (e < TS * FH) tile[e] = nfoot[q];
+        }
+        const uint32_t cmask = nmask, c0 = nrgb[0], c1 = nrgb[1], c2 = nrgb[2];
+        if (f + 1 < F) fetch(f + 1);
+        __syncthreads();
+        float centre[4];
+        uint32_t ok = reliable4<1, TS>(tile, tx, ty, u, v, H, W, centre);
+        // colour bytes of the four pixels: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3
+        const uint32_t cr[4] = {c0 & 255u, c0 >> 24, (c1 >> 16) & 255u, (c2 >> 8) & 255u};
+        const uint32_t cg[4] = {(c0 >> 8) & 255u, c1 & 255u, c1 >> 24, (c2 >> 16) & 255u};
+        const uint32_t cb[4] = {(c0 >> 16) & 255u, (c1 >> 8) & 255u, c2 & 255u, c2 >> 24};
+        const long long i1 = first_index + f + 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool take = inside && ((ok >> k) & 1u) != 0u && ((cmask >> (8 * k)) & 255u) == 0u;
+            const float t0 = take ? centre[k] : 0.0f;
+            const float t1 = take ? lut[cr[k]] : 0.0f;
+            const float t2 = take ? lut[cg[k]] : 0.0f;
+            const float t3 = take ? lut[cb[k]] : 0.0f;
+            cnt[k] += take ? 1 : 0;
+            acc[k][0][0] = acc[k][0][0] + t0;
+            acc[k][0][1] = acc[k][0][1] + t1;
+            acc[k][0][2] = acc[k][0][2] + t2;
+            acc[k][0][3] = acc[k][0][3] + t3;
+        }
+        if ((i1 & 15) == 0) {  // frame-index conditions: the same for every thread
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[k][1][q] = acc[k][1][q] + acc[k][0][q];
+                    acc[k][0][q] = 0.0f;
+                }
+            if ((i1 & 0xF0) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[k][2][q] = acc[k][2][q] + acc[k][1][q];
+                        acc[k][1][q] = 0.0f;
+                    }
+                if ((i1 & 0xF00) == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[k][3][q] = acc[k][3][q] + acc[k][2][q];
+                            acc[k][2][q] = 0.0f;
+                        }
+                }
+            }
+        }
+    }
+    if (inside) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) state[(size_t)(l * 4 + q) * HW + pix + k] = acc[k][l][q];
+            ((int*)state)[16 * HW + pix + k] = cnt[k];
+        }
+    }
+}
+
 __device__ __forceinline__ float folded_sum(const float* __restrict__ state, size_t HW, size_t pix, int q) {
     float s = state[(size_t)q * HW + pix];
     s = s + state[(size_t)(4 + q) * HW + pix];
@@ -705,6 +879,12 @@ extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, 
     if (first_index + F >= (1ll << 19))
         return ep_host::fail(EGOPRIOR_E_UNSUPPORTED, "more than 2^19 frames changes the cascade run length");
     if (F == 0) return 0;
+    const bool aligned4 = (((uintptr_t)d_rgb | (uintptr_t)d_mask) & 3u) == 0;  // the fast kernel reads 32-bit words
+    if (W % 4 == 0 && aligned4 && (int64_t)H * W < (1ll << 31)) {
+        EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate_row4, dim3((W + 63) / 64, (H + 15) / 16), dim3(256), 0,
+                  (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask, F, (long long)first_index, H, W);
+        return ep_host::check_launch("meanbg_accumulate");
+    }
     const dim3 grid((W + EP_MASK_SX - 1) / EP_MASK_SX, (H + EP_MASK_SY - 1) / EP_MASK_SY);
     EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
                        F, (long long)first_index, H, W);

@@ -299,6 +299,24 @@ class Engine:
                                                       _ptr(ds), _ptr(status), _ptr(ws), ws.numel(), _stream()))
         return dict(image=img, image_f32=f32, idx=idx, zbuf=zb, dists=ds, status=status)
 
+    # -- output side ---------------------------------------------------------------------------------------------------
+    def white_pixel_counts(self, frames, threshold: float = 30.0, want_masks: bool = False):
+        """Per-frame count of pixels whose grey value 0.299 r + 0.587 g + 0.114 b reaches `threshold`
+        (data_preprocess/scripts/postprocess_render_dir.py:17-31, 46-67).  frames: (n, H, W, 3) uint8 (device tensor or
+        array).  Returns the int32 device tensor of counts, and the (n, H, W) 0/255 masks if asked for."""
+        fr = self.to_device(frames, torch.uint8)
+        if fr.dim() == 3:
+            fr = fr[None]
+        if fr.dim() != 4 or fr.shape[-1] != 3:
+            raise ValueError("frames must be (n, H, W, 3) uint8")
+        n, H, W, _ = fr.shape
+        counts = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+        masks = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if want_masks else None
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_white_pixel_counts(_ptr(fr), n, H, W, float(threshold), _ptr(counts), _ptr(masks),
+                                                     _stream()))
+        return (counts[:n], masks) if want_masks else counts[:n]
+
     def render_frame(self, cam: Camera, rp: RasterParams, a: DeviceCloud, b: Optional[DeviceCloud] = None,
                      want_f32: bool = False, want_fragments: bool = False, out_image: Optional[torch.Tensor] = None):
         H, W = cam.H, cam.W

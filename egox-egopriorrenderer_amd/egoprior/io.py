@@ -249,6 +249,19 @@ def encode_png_gray(img: np.ndarray) -> bytes:
             + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
+def encode_png_rgb(img: np.ndarray) -> bytes:
+    """8-bit RGB PNG (filter 0) of an (H, W, 3) uint8 image."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w, _ = img.shape
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w, mask_as_png_zip: bool = True):
     """Writes a sequence in the ViPE layout using the array twins for rgb and depth (no codec needed) and, by default,
     the reference's zip-of-PNG container for the instance masks.  depth is stored as float16 like the EXR HALF files."""

@@ -480,6 +480,11 @@ def get_parser():
     p.add_argument("--fish_eye_rendering", action="store_true", help="Enable fish-eye rendering")
     p.add_argument("--online_calibration_path", type=str, default=None,
                    help="(Optional) online_calibration.jsonl with the real Aria distortion coefficients")
+    # extras of this implementation, all opt-in
+    p.add_argument("--dump_frames", action="store_true",
+                   help="also write frame_%%06d.png next to the video and print the white-pixel metrics the batch "
+                        "scripts derive from such a dump (data_preprocess/scripts/postprocess_render_dir.py)")
+    p.add_argument("--white_threshold", type=float, default=30.0, help="grey threshold of the white-pixel metrics")
     return p
 
 
@@ -541,6 +546,29 @@ def main(argv=None):
         only_bg=args.only_bg)
     out = write_video(Path(args.out_dir) / "ego_Prior.mp4", frames, fps=30)
     logger.info(f"Rendering complete. Saved {len(frames)} frames to {out}")
+    if args.dump_frames and frames:
+        dump_frames_and_metrics(frames, args.out_dir, args.white_threshold)
+
+
+def dump_frames_and_metrics(frames, out_dir, threshold: float = 30.0, write_masks: bool = True):
+    """What infer_vipe_all_takes.sh:351-356 (ffmpeg frame dump) followed by postprocess_render_dir.py:34-67 produce:
+    frame_%06d.png (ffmpeg numbers from 1), frame_%06d_mask.png and the three metric lines.  The grey conversion and the
+    counts run on the GPU; returns (total_white_pixels, frames_with_any_white, num_frames)."""
+    from .io import encode_png_gray, encode_png_rgb
+    E = _engine()
+    stack = np.stack([np.asarray(f, dtype=np.uint8) for f in frames])
+    counts, masks = E.white_pixel_counts(stack, threshold, want_masks=True)
+    counts, masks = counts.cpu().numpy(), masks.cpu().numpy()
+    out_dir = Path(out_dir)
+    for i, f in enumerate(frames):
+        (out_dir / f"frame_{i + 1:06d}.png").write_bytes(encode_png_rgb(np.asarray(f, dtype=np.uint8)))
+        if write_masks:
+            (out_dir / f"frame_{i + 1:06d}_mask.png").write_bytes(encode_png_gray(masks[i]))
+    total, any_white = int(counts.astype(np.int64).sum()), int((counts > 0).sum())
+    print(f"total_white_pixels={total}")
+    print(f"frames_with_any_white={any_white}")
+    print(f"num_frames={len(frames)}")
+    return total, any_white, len(frames)
 
 
 if __name__ == "__main__":

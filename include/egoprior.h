@@ -175,6 +175,16 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
                           void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * White-pixel metric of finished frames, data_preprocess/scripts/postprocess_render_dir.py:17-31 (grey conversion and
+ * threshold) and :46-67 (per-frame counts that the batch script sums up to pick the best camera), computed on the
+ * uint8 frames where the renderer left them instead of on PNG files dumped by ffmpeg.
+ * d_frames: n_frames x H x W x 3 uint8; d_counts[n_frames] receives the number of pixels with
+ * float32(0.299 r + 0.587 g + 0.114 b) >= threshold; d_masks (optional, n_frames x H x W) receives 0 / 255.
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32_t H, int32_t W, float threshold,
+                                int32_t* d_counts, uint8_t* d_masks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Per-kernel timing for benchmarks (no counterpart in the reference, which has no profiling on this path).
  * Between _begin and _end every kernel launched by the calls above on the calling thread is bracketed by a pair of
  * HIP events on its launch stream.  _end waits for them, sums the elapsed time per kernel name and returns, for up to
@@ -182,9 +192,10 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
  * with the device: keep it out of timed regions.
  * --------------------------------------------------------------------------------------------------------------- */
 int egoprior_profile_begin(void);
-/* Process-wide tuning / test switches (no counterpart in the reference): "splat_variant" (0 default sweep kernel,
- * 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks to force its multi-chunk path on small
- * inputs, 3 sweep kernel with 512-record chunks), "bin_lds" (1 default: per-workgroup LDS aggregation in binning). */
+/* Process-wide tuning / test switches (no counterpart in the reference): "splat_variant" (0 default sweep kernel with
+ * 512-record chunks, 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks to force its multi-chunk
+ * path on small inputs, 3 with 1024-record chunks, 6 with sampled bucket boundaries), "bin_lds" (1 default: the tile
+ * counts are aggregated per workgroup in LDS, 0: straight global atomics). */
 int egoprior_set_option(const char* name, int32_t value);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
                          int32_t* n_kernels);

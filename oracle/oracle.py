@@ -476,3 +476,17 @@ def render_points_fisheye(points_world, colors_world, T_w2c, f_px, cx_px, cy_px,
     if return_fragments:
         return img, dict(ndc=ndc, idx=idx, zbuf=zbuf, dists=dists, cols=cols, radius=r)
     return img
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# output side: white-pixel metric
+# --------------------------------------------------------------------------------------------------------------------
+def white_pixel_mask(frame_u8, threshold: float = 30.0):
+    """data_preprocess/scripts/postprocess_render_dir.py:17-31: grey = float32(0.299 r + 0.587 g + 0.114 b) with the
+    products and sums in float64 (uint8 arrays times Python floats), mask = grey >= threshold; returns (0/1 uint8 mask,
+    0/255 uint8 picture).  :60-63: the metric is mask.sum() per frame."""
+    arr = np.asarray(frame_u8)
+    r, g, b = arr[..., 0], arr[..., 1], arr[..., 2]
+    gray = (0.299 * r + 0.587 * g + 0.114 * b).astype(F32)
+    logical = (gray >= F32(threshold)).astype(np.uint8)
+    return logical, (logical * 255).astype(np.uint8)

@@ -140,3 +140,27 @@ def test_cli_end_to_end(clip_dir, tmp_path, mode):
             bad = (np.abs(frames[f].astype(int) - ref.astype(int)).max(axis=2) > 1).mean()
             worst = max(worst, bad)
     assert worst < 2e-3
+
+
+def test_white_pixel_metrics_match_the_numpy_recipe(engine, tmp_path):
+    """The output-side metric (postprocess_render_dir.py) on the GPU against its numpy restatement, bit for bit,
+    including values that sit exactly on the threshold."""
+    from egoprior import render_vipe_pointcloud as rv
+    from egoprior.io import decode_png_gray
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (5, 37, 53, 3), dtype=np.uint8)
+    frames[1] = 0                                   # a frame without any white pixel
+    frames[2, :, :, :] = 30                         # grey exactly 30 -> counts (>=)
+    frames[3, :8] = [29, 30, 31]                    # grey 29.8..: below
+    frames[3, 8:16] = [100, 0, 2]                   # 0.299*100 + 0.228 = 30.128
+    counts, masks = engine.white_pixel_counts(frames, 30.0, want_masks=True)
+    for i in range(5):
+        logical, vis = O.white_pixel_mask(frames[i], 30.0)
+        assert counts[i].item() == int(logical.sum())
+        assert np.array_equal(masks[i].cpu().numpy(), vis)
+    assert counts[1].item() == 0 and counts[2].item() == 37 * 53
+    total, any_white, n = rv.dump_frames_and_metrics(list(frames), tmp_path, 30.0)
+    assert (total, any_white, n) == (int(counts.sum().item()), 4, 5)
+    assert np.array_equal(decode_png_gray((tmp_path / "frame_000003_mask.png").read_bytes()),
+                          O.white_pixel_mask(frames[2], 30.0)[1])
+    assert (tmp_path / "frame_000005.png").exists() and not (tmp_path / "frame_000006.png").exists()

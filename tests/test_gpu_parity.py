@@ -404,6 +404,22 @@ def test_mean_background(engine, F):
     assert np.array_equal(cloud.to_numpy()[1], ref_cols)
 
 
+@pytest.mark.parametrize("size", [(64, 126), (45, 77), (16, 8)])
+def test_mean_background_ragged_sizes(engine, size):
+    """Widths that are not a multiple of 4 take the one-pixel-per-thread kernel, small and odd sizes have partial
+    workgroups on both axes; the oracle's plain left-to-right sums equal the cascade for fewer than 16 frames."""
+    Hh, Ww = size
+    F = 11
+    clip = synthetic_clip(Hh, Ww, F)
+    ref_d, ref_c = O.mean_background(clip["depth"], clip["rgb"], clip["mask"])
+    st = engine.meanbg_new_state(Hh, Ww)
+    engine.meanbg_accumulate(st, clip["depth"][:6], clip["rgb"][:6], clip["mask"][:6], 0)
+    engine.meanbg_accumulate(st, clip["depth"][6:], clip["rgb"][6:], clip["mask"][6:], 6)
+    md, mc = engine.meanbg_finalize(st)
+    assert np.array_equal(md.cpu().numpy(), ref_d)
+    assert np.array_equal(mc.cpu().numpy(), np.clip(ref_c * F32(255), 0, 255).astype(np.uint8))
+
+
 def test_mean_background_matches_torch_nanmean(engine):
     """The same reduction through torch.nanmean on CPU (what the reference calls)."""
     clip = synthetic_clip(72, 128, 19)

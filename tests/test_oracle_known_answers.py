@@ -153,3 +153,18 @@ def test_radius_rule():
     assert O.radius_ndc(1000, 448, 448) == 0.25 and O.radius_ndc(0, 448, 448) == 1e-5
     r = O.radius_ndc(5.0, 448, 448)
     assert F32(r) * F32(r) == F32(4.9824617e-4) and F32(r * r) == F32(4.9824617e-4)
+
+
+def test_white_pixel_mask_known_answers():
+    """Grey weights sum to 1, so a uniform colour v has grey v (up to float64 rounding, then float32): 30 passes a
+    threshold of 30, 29 does not; pure red needs 101 (0.299 * 101 = 30.199)."""
+    f = np.zeros((2, 3, 3), dtype=np.uint8)
+    f[0, 0] = 30
+    f[0, 1] = 29
+    f[0, 2] = [101, 0, 0]
+    f[1, 0] = [100, 0, 0]
+    f[1, 1] = [0, 52, 0]   # 0.587 * 52 = 30.524
+    f[1, 2] = [0, 0, 255]  # 0.114 * 255 = 29.07
+    logical, vis = O.white_pixel_mask(f, 30.0)
+    assert logical.tolist() == [[1, 0, 1], [0, 1, 0]]
+    assert vis.max() == 255 and vis.dtype == np.uint8

@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--skip-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (egoprior_set_option)")
+    ap.add_argument("--depth-f16", action="store_true",
+                    help="keep the exo depth maps in HBM as float16 (the precision of the EXR artifacts) instead of float32")
     ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight: consecutive frames go round-robin to this many HIP streams, each with its "
                          "own dynamic-point buffer and workspaces (frames are independent of one another)")
@@ -88,7 +90,7 @@ def main():
 
     # ---- synthetic clip straight into HBM --------------------------------------------------------------------------
     t0 = time.time()
-    depth = torch.empty((Fl, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((Fl, H, W), dtype=torch.float16 if args.depth_f16 else torch.float32, device=dev)
     rgb = torch.empty((Fl, H, W, 3), dtype=torch.uint8, device=dev)
     mask = torch.empty((Fl, H, W), dtype=torch.uint8, device=dev)
     for c0 in range(0, Fl, 25):
@@ -212,7 +214,7 @@ def main():
     n_avg = pts_entering / n_frames_total  # points entering the binning stage per frame
     n_in_avg = n_bg + n_dyn_sum / n_frames_total
     alg_bytes = {
-        "k_reliable_flags": 4 * H * W + 2 * ns,
+        "k_reliable_flags": (2 if args.depth_f16 else 4) * H * W + 2 * ns,
         "k_flag_block_count": ns,
         "k_block_scan": 0,
         "k_unproject_scatter": ns + (n_dyn_sum / n_frames_total) * (16 + 7),
@@ -274,7 +276,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {W}x{H} exo depth+RGB+mask, subsample {s}, mean-bg static cloud "
                                f"({n_bg} pts) + per-frame dynamic points -> {He}x{We} pinhole ego, point_size "
                                f"{args.point_size}, K=20, {Fl} exo frames/rank resident in HBM",
-                   "exo": [H, W], "ego": [He, We], "point_size": args.point_size, "subsample": s,
+                   "exo": [H, W], "ego": [He, We], "point_size": args.point_size, "subsample": s, "depth_dtype": "f16" if args.depth_f16 else "f32",
                    "frames_per_rank": Fl, "static_points": n_bg, "frames_in_flight": pipe.n_slots,
                    "parallelism": f"frames sharded x{world}"},
         "gpoints_per_s": round(pts_entering / elapsed / 1e9, 4),

@@ -8,7 +8,14 @@
 #include "egoprior_common.h"
 #include "egoprior_host.h"
 
+#include <hip/hip_fp16.h>
+
 namespace ep {
+
+// Depth maps come as float32 or, as the EXR files store them (vipe/utils/io.py:274-277), as float16; the conversion to
+// float32 is exact, so both give the same bits downstream.
+__device__ __forceinline__ float ldd(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float ldd(const __half* p, size_t i) { return __half2float(p[i]); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // 5x5 reliability test on an LDS tile (vipe/utils/depth.py:385-422)
@@ -58,14 +65,15 @@ __device__ __forceinline__ bool reliable_at(const float* __restrict__ tile, int 
 }
 
 // cooperative clamped load of a (fw x fh) footprint whose top-left pixel is (x0, y0)
-__device__ __forceinline__ void load_footprint(float* __restrict__ tile, const float* __restrict__ depth, int H, int W,
+template <typename DT>
+__device__ __forceinline__ void load_footprint(float* __restrict__ tile, const DT* __restrict__ depth, int H, int W,
                                                int x0, int y0, int fw, int fh) {
     for (int e = threadIdx.x; e < fw * fh; e += blockDim.x) {
         const int ly = e / fw, lx = e - ly * fw;
         int yy = y0 + ly, xx = x0 + lx;
         yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
         xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-        tile[e] = depth[(size_t)yy * W + xx];
+        tile[e] = ldd(depth, (size_t)yy * W + xx);
     }
 }
 
@@ -74,7 +82,8 @@ __device__ __forceinline__ void load_footprint(float* __restrict__ tile, const f
 
 // flags[j*Ws + i] = reliable(depth)[s*j, s*i] && select(mask[s*j, s*i]); one thread per sample, 32x8 samples per
 // block.  Dynamic LDS: (31*s+5)*(7*s+5) floats.
-__global__ void __launch_bounds__(256) k_reliable_flags(const float* __restrict__ depth,
+template <typename DT>
+__global__ void __launch_bounds__(256) k_reliable_flags(const DT* __restrict__ depth,
                                                         const uint8_t* __restrict__ mask, int H, int W, int s, int Hs,
                                                         int Ws, int select, uint8_t* __restrict__ flags) {
     extern __shared__ float tile[];
@@ -207,8 +216,8 @@ __device__ __forceinline__ uint32_t reliable4(const float* __restrict__ tile, in
 // Subsample factors 1 and 2: 64 x 16 samples per block, four horizontally adjacent samples per thread.  A thread pulls
 // each of its five window rows out of the LDS tile once, as 16-byte reads, and feeds all four windows from registers, so a
 // sample costs 2.5 (S=1) or 3.75 (S=2) LDS reads instead of 25.  Same arithmetic, tap by tap, as reliable_at().
-template <int S>
-__global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __restrict__ depth,
+template <int S, typename DT>
+__global__ void __launch_bounds__(256) k_reliable_flags_row4(const DT* __restrict__ depth,
                                                              const uint8_t* __restrict__ mask, int H, int W, int Hs,
                                                              int Ws, int select, uint8_t* __restrict__ flags) {
     constexpr int BX = 64, BY = 16;
@@ -229,7 +238,7 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __rest
             int yy = y0 + ly, xx = x0 + lx;
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
             xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            tmp[q] = depth[(size_t)yy * W + xx];
+            tmp[q] = ldd(depth, (size_t)yy * W + xx);
         }
 #pragma unroll
         for (int q = 0; q < NL; ++q) {
@@ -269,7 +278,8 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const float* __rest
 }
 
 // window taps straight from global memory (large subsample factors, where windows do not overlap)
-__global__ void __launch_bounds__(256) k_reliable_flags_direct(const float* __restrict__ depth,
+template <typename DT>
+__global__ void __launch_bounds__(256) k_reliable_flags_direct(const DT* __restrict__ depth,
                                                                const uint8_t* __restrict__ mask, int H, int W, int s,
                                                                int Hs, int Ws, int select,
                                                                uint8_t* __restrict__ flags) {
@@ -285,7 +295,7 @@ __global__ void __launch_bounds__(256) k_reliable_flags_direct(const float* __re
             int yy = v + kh - 2, xx = u + kw - 2;
             yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
             xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-            win[kh * 5 + kw] = depth[(size_t)yy * W + xx];
+            win[kh * 5 + kw] = ldd(depth, (size_t)yy * W + xx);
         }
     }
     bool ok = reliable_at(win, 5, 0, 0, u, v, H, W);
@@ -377,8 +387,9 @@ __device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict
 }
 
 // flags + block offsets -> compacted records: rays * depth, c2w (float32), exo->world (float64), colour bytes
+template <typename DT>
 __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_params p, int Hs, int Ws,
-                                                           const float* __restrict__ depth,
+                                                           const DT* __restrict__ depth,
                                                            const uint8_t* __restrict__ rgb,
                                                            const uint8_t* __restrict__ flags,
                                                            const uint32_t* __restrict__ block_offset,
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
         const int j = (int)(e / Ws), i = (int)(e - (int64_t)j * Ws);
         const int u = i * p.subsample, v = j * p.subsample;
         const size_t pix = (size_t)v * p.W + u;
-        const float d = depth[pix];
+        const float d = ldd(depth, pix);
         const float X = ((float)u - p.cx) / p.fx;
         const float Y = ((float)v - p.cy) / p.fy;
         const float pcx = X * d, pcy = Y * d, pcz = 1.0f * d;
@@ -481,7 +492,8 @@ __global__ void __launch_bounds__(256) k_filter_scatter(const float* __restrict_
 // One thread owns one pixel and walks the frames; per frame the block stages the 5x5 footprint of its 32x8 pixels in
 // LDS.  Sums follow ATen's CPU cascade order (see oracle.cascade_nansum): level 0 takes the terms one by one and is
 // flushed upward after every 16th term.
-__global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ state, const float* __restrict__ depth,
+template <typename DT>
+__global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ state, const DT* __restrict__ depth,
                                                            const uint8_t* __restrict__ rgb,
                                                            const uint8_t* __restrict__ mask, int F,
                                                            long long first_index, int H, int W) {
@@ -505,7 +517,7 @@ __global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ s
     if (inside) cnt = ((const int*)state)[16 * HW + pix];
 
     for (int f = 0; f < F; ++f) {
-        const float* dfr = depth + (size_t)f * HW;
+        const DT* dfr = depth + (size_t)f * HW;
         __syncthreads();
         load_footprint(tile, dfr, H, W, x0 - 2, y0 - 2, fw, fh);
         __syncthreads();
@@ -562,8 +574,9 @@ __global__ void __launch_bounds__(256) k_meanbg_accumulate(float* __restrict__ s
 // frame's depth footprint, mask bytes and colour bytes are fetched into registers while the current frame is worked on,
 // so a frame costs its arithmetic and not two exposed memory latencies.  Per pixel the terms are added in the same
 // order as in the one-pixel-per-thread kernel.
+template <typename DT>
 __global__ void __launch_bounds__(256) k_meanbg_accumulate_row4(float* __restrict__ state,
-                                                                const float* __restrict__ depth,
+                                                                const DT* __restrict__ depth,
                                                                 const uint8_t* __restrict__ rgb,
                                                                 const uint8_t* __restrict__ mask, int F,
                                                                 long long first_index, int H, int W) {
@@ -606,9 +619,9 @@ __global__ void __launch_bounds__(256) k_meanbg_accumulate_row4(float* __restric
     float nfoot[NL];
     uint32_t nmask = 0u, nrgb[3] = {0u, 0u, 0u};
     auto fetch = [&](int f) {
-        const float* dfr = depth + (size_t)f * HW;
+        const DT* dfr = depth + (size_t)f * HW;
 #pragma unroll
-        for (int q = 0; q < NL; ++q) nfoot[q] = dfr[foff[q]];
+        for (int q = 0; q < NL; ++q) nfoot[q] = ldd(dfr, foff[q]);
         if (mask != nullptr) nmask = *reinterpret_cast<const uint32_t*>(mask + (size_t)f * HW + pix);
         const uint32_t* c = reinterpret_cast<const uint32_t*>(rgb + ((size_t)f * HW + pix) * 3);  // 12 bytes, 4-aligned
         nrgb[0] = c[0];
@@ -776,35 +789,45 @@ bool carve_compact_ws(void* ws, size_t bytes, int64_t n, CompactWs& c) {
     return true;
 }
 
-int launch_flags(const float* d_depth, const uint8_t* d_mask, int H, int W, int s, int select, uint8_t* flags,
+template <typename DT>
+int launch_flags(const DT* d_depth, const uint8_t* d_mask, int H, int W, int s, int select, uint8_t* flags,
                  hipStream_t st) {
     const int Hs = (H + s - 1) / s, Ws = (W + s - 1) / s;
     if (s == 1) {
-        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags_row4<1>, dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
+        EP_LAUNCH("k_reliable_flags", (ep::k_reliable_flags_row4<1, DT>), dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
                   d_depth, d_mask, H, W, Hs, Ws, select, flags);
     } else if (s == 2) {
-        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags_row4<2>, dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
+        EP_LAUNCH("k_reliable_flags", (ep::k_reliable_flags_row4<2, DT>), dim3((Ws + 63) / 64, (Hs + 15) / 16), dim3(256), 0, st,
                   d_depth, d_mask, H, W, Hs, Ws, select, flags);
     } else if (s <= 4) {
         const int fw = (EP_MASK_SX - 1) * s + 5, fh = (EP_MASK_SY - 1) * s + 5;
         const dim3 grid((Ws + EP_MASK_SX - 1) / EP_MASK_SX, (Hs + EP_MASK_SY - 1) / EP_MASK_SY);
-        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,
+        EP_LAUNCH("k_reliable_flags", ep::k_reliable_flags<DT>, grid, dim3(256), sizeof(float) * (size_t)fw * fh, st, d_depth, d_mask,
                            H, W, s, Hs, Ws, select, flags);
     } else {
         const int64_t n = (int64_t)Hs * Ws;
-        EP_LAUNCH("k_reliable_flags_direct", ep::k_reliable_flags_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_depth,
+        EP_LAUNCH("k_reliable_flags_direct", ep::k_reliable_flags_direct<DT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_depth,
                            d_mask, H, W, s, Hs, Ws, select, flags);
     }
     return ep_host::check_launch("reliable_flags");
+}
+
+template <typename DT>
+int reliable_depth_mask_t(const DT* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out, void* stream) {
+    if (d_depth == nullptr || d_mask_out == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad image size");
+    return launch_flags(d_depth, nullptr, H, W, 1, EGOPRIOR_SELECT_ALL, d_mask_out, (hipStream_t)stream);
 }
 
 }  // namespace
 
 extern "C" int egoprior_reliable_depth_mask(const float* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out,
                                             void* stream) {
-    if (d_depth == nullptr || d_mask_out == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
-    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad image size");
-    return launch_flags(d_depth, nullptr, H, W, 1, EGOPRIOR_SELECT_ALL, d_mask_out, (hipStream_t)stream);
+    return reliable_depth_mask_t(d_depth, H, W, d_mask_out, stream);
+}
+extern "C" int egoprior_reliable_depth_mask_f16(const uint16_t* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out,
+                                                void* stream) {
+    return reliable_depth_mask_t(reinterpret_cast<const __half*>(d_depth), H, W, d_mask_out, stream);
 }
 
 extern "C" size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32_t subsample) {
@@ -813,10 +836,11 @@ extern "C" size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32
     return compact_ws_bytes(Hs * Ws);
 }
 
-extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
-                                        const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
-                                        int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes,
-                                        void* stream) {
+namespace {
+template <typename DT>
+int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, const uint8_t* d_rgb,
+                      const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
+                      int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (p == nullptr || d_depth == nullptr || d_rgb == nullptr || d_points == nullptr || d_count == nullptr)
         return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (p->H <= 0 || p->W <= 0 || p->subsample <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad frame geometry");
@@ -833,9 +857,25 @@ extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, cons
     EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
     EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
-    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
+    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
                        c.block_offset, d_points, d_xyz64, d_flags);
     return ep_host::check_launch("unproject_frame");
+}
+}  // namespace
+
+extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
+                                        const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
+                                        int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes,
+                                        void* stream) {
+    return unproject_frame_t(p, d_depth, d_rgb, d_mask, d_points, d_xyz64, d_count, d_flags, d_workspace,
+                             workspace_bytes, stream);
+}
+extern "C" int egoprior_unproject_frame_f16(const egoprior_unproject_params* p, const uint16_t* d_depth,
+                                            const uint8_t* d_rgb, const uint8_t* d_mask, egoprior_point* d_points,
+                                            double* d_xyz64, int32_t* d_count, int32_t* d_flags, void* d_workspace,
+                                            size_t workspace_bytes, void* stream) {
+    return unproject_frame_t(p, reinterpret_cast<const __half*>(d_depth), d_rgb, d_mask, d_points, d_xyz64, d_count,
+                             d_flags, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t egoprior_filter_workspace_bytes(int64_t N) { return N < 0 ? 0 : compact_ws_bytes(N > 0 ? N : 1); }
@@ -870,9 +910,10 @@ extern "C" size_t egoprior_meanbg_state_bytes(int32_t H, int32_t W) {
     return (size_t)17 * (size_t)H * (size_t)W * sizeof(float);
 }
 
-extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, const uint8_t* d_rgb,
-                                          const uint8_t* d_mask, int32_t F, int64_t first_index, int32_t H, int32_t W,
-                                          void* stream) {
+namespace {
+template <typename DT>
+int meanbg_accumulate_t(float* d_state, const DT* d_depth, const uint8_t* d_rgb, const uint8_t* d_mask, int32_t F,
+                        int64_t first_index, int32_t H, int32_t W, void* stream) {
     if (d_state == nullptr || d_depth == nullptr || d_rgb == nullptr)
         return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (H <= 0 || W <= 0 || F < 0 || first_index < 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
@@ -881,14 +922,27 @@ extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, 
     if (F == 0) return 0;
     const bool aligned4 = (((uintptr_t)d_rgb | (uintptr_t)d_mask) & 3u) == 0;  // the fast kernel reads 32-bit words
     if (W % 4 == 0 && aligned4 && (int64_t)H * W < (1ll << 31)) {
-        EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate_row4, dim3((W + 63) / 64, (H + 15) / 16), dim3(256), 0,
+        EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate_row4<DT>, dim3((W + 63) / 64, (H + 15) / 16), dim3(256), 0,
                   (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask, F, (long long)first_index, H, W);
         return ep_host::check_launch("meanbg_accumulate");
     }
     const dim3 grid((W + EP_MASK_SX - 1) / EP_MASK_SX, (H + EP_MASK_SY - 1) / EP_MASK_SY);
-    EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
+    EP_LAUNCH("k_meanbg_accumulate", ep::k_meanbg_accumulate<DT>, grid, dim3(256), 0, (hipStream_t)stream, d_state, d_depth, d_rgb, d_mask,
                        F, (long long)first_index, H, W);
     return ep_host::check_launch("meanbg_accumulate");
+}
+}  // namespace
+
+extern "C" int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, const uint8_t* d_rgb,
+                                          const uint8_t* d_mask, int32_t F, int64_t first_index, int32_t H, int32_t W,
+                                          void* stream) {
+    return meanbg_accumulate_t(d_state, d_depth, d_rgb, d_mask, F, first_index, H, W, stream);
+}
+extern "C" int egoprior_meanbg_accumulate_f16(float* d_state, const uint16_t* d_depth, const uint8_t* d_rgb,
+                                              const uint8_t* d_mask, int32_t F, int64_t first_index, int32_t H,
+                                              int32_t W, void* stream) {
+    return meanbg_accumulate_t(d_state, reinterpret_cast<const __half*>(d_depth), d_rgb, d_mask, F, first_index, H, W,
+                               stream);
 }
 
 extern "C" int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t W, float* d_mean_depth,

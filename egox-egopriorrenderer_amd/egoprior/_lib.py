@@ -51,11 +51,15 @@ SIGNATURES = {
     "egoprior_last_error": (C.c_char_p, []),
     "egoprior_abi_version": (C.c_int, []),
     "egoprior_reliable_depth_mask": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "egoprior_reliable_depth_mask_f16": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "egoprior_unproject_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "egoprior_unproject_frame": (C.c_int, [C.POINTER(UnprojectParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                            _vp]),
+    "egoprior_unproject_frame_f16": (C.c_int, [C.POINTER(UnprojectParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _sz, _vp]),
     "egoprior_meanbg_state_bytes": (_sz, [_i32, _i32]),
     "egoprior_meanbg_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "egoprior_meanbg_accumulate_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "egoprior_meanbg_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "egoprior_meanbg_export": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "egoprior_meanbg_import": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),

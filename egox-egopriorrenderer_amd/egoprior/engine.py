@@ -163,6 +163,15 @@ class Engine:
             flags=torch.zeros(1, dtype=torch.int32, device=self.device),
             xyz64=torch.empty((cap, 3), dtype=torch.float64, device=self.device) if want_xyz64 else None)
 
+    def depth_to_device(self, depth) -> torch.Tensor:
+        """Depth maps stay float16 if they arrive as float16 (the precision the artifacts are stored in): the kernels
+        widen them on the fly, which is exact.  Anything else becomes float32."""
+        is_f16 = (depth.dtype == torch.float16) if isinstance(depth, torch.Tensor) else (np.asarray(depth).dtype == np.float16)
+        return self.to_device(depth, torch.float16 if is_f16 else torch.float32)
+
+    def _by_depth(self, name: str, d: torch.Tensor):
+        return getattr(self.L, name + "_f16") if d.dtype == torch.float16 else getattr(self.L, name)
+
     def to_device(self, a, dtype) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
@@ -173,18 +182,18 @@ class Engine:
 
     # -- R5 -----------------------------------------------------------------------------------------------------------
     def reliable_depth_mask(self, depth) -> torch.Tensor:
-        d = self.to_device(depth, torch.float32)
+        d = self.depth_to_device(depth)
         H, W = d.shape
         out = torch.empty((H, W), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            check(self.L.egoprior_reliable_depth_mask(_ptr(d), H, W, _ptr(out), _stream()))
+            check(self._by_depth("egoprior_reliable_depth_mask", d)(_ptr(d), H, W, _ptr(out), _stream()))
         return out.bool()
 
     # -- R6 / R7 ------------------------------------------------------------------------------------------------------
     def unproject_frame(self, depth, rgb, mask, intr, c2w, T_cam_to_world, subsample: int = 2,
                         select: int = _lib.SELECT_STATIC, out: Optional[DeviceCloud] = None,
                         want_xyz64: bool = False) -> DeviceCloud:
-        d = self.to_device(depth, torch.float32)
+        d = self.depth_to_device(depth)
         c = self.to_device(rgb, torch.uint8)
         m = None if mask is None else self.to_device(mask, torch.uint8)
         H, W = d.shape
@@ -202,9 +211,9 @@ class Engine:
         nbytes = self.L.egoprior_unproject_workspace_bytes(H, W, s)
         ws = self._workspace("unproject", nbytes)
         with torch.cuda.device(self.device):
-            check(self.L.egoprior_unproject_frame(C.byref(p), _ptr(d), _ptr(c), _ptr(m), _ptr(out.points),
-                                                  _ptr(out.xyz64) if want_xyz64 else None, _ptr(out.count),
-                                                  _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
+            check(self._by_depth("egoprior_unproject_frame", d)(
+                C.byref(p), _ptr(d), _ptr(c), _ptr(m), _ptr(out.points), _ptr(out.xyz64) if want_xyz64 else None,
+                _ptr(out.count), _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
         return out
 
     # -- render-entry filters -----------------------------------------------------------------------------------------
@@ -227,7 +236,7 @@ class Engine:
         return torch.zeros((17, H, W), dtype=torch.float32, device=self.device)
 
     def meanbg_accumulate(self, state: torch.Tensor, depth, rgb, mask, first_index: int = 0) -> None:
-        d = self.to_device(depth, torch.float32)
+        d = self.depth_to_device(depth)
         c = self.to_device(rgb, torch.uint8)
         m = None if mask is None else self.to_device(mask, torch.uint8)
         if d.dim() == 2:
@@ -237,8 +246,8 @@ class Engine:
         if tuple(state.shape) != (17, H, W):
             raise ValueError("state does not match the frame size")
         with torch.cuda.device(self.device):
-            check(self.L.egoprior_meanbg_accumulate(_ptr(state), _ptr(d), _ptr(c), _ptr(m), Fn, int(first_index), H, W,
-                                                    _stream()))
+            check(self._by_depth("egoprior_meanbg_accumulate", d)(_ptr(state), _ptr(d), _ptr(c), _ptr(m), Fn,
+                                                                  int(first_index), H, W, _stream()))
 
     def meanbg_finalize(self, state: torch.Tensor):
         _, H, W = state.shape
@@ -435,9 +444,11 @@ class FramePipeline:
                     or tuple(rgb.shape) != (H, W, 3) or (mask is not None and tuple(mask.shape) != (H, W)):
                 raise ValueError("exo frame does not match the pipeline's exo_hw / subsample")
             d = self.dyns[k]
-            check(self.L.egoprior_unproject_frame(C.byref(up), _ptr(depth), _ptr(rgb), _ptr(mask), _ptr(d.points), None,
-                                                  _ptr(d.count), _ptr(d.flags), _ptr(self.ws_u[k]),
-                                                  self.ws_u[k].numel(), self._h[k]))
+            if depth.dtype not in (torch.float32, torch.float16) or not depth.is_contiguous():
+                raise ValueError("depth must be a contiguous float32 or float16 tensor")
+            check(self.E._by_depth("egoprior_unproject_frame", depth)(
+                C.byref(up), _ptr(depth), _ptr(rgb), _ptr(mask), _ptr(d.points), None, _ptr(d.count), _ptr(d.flags),
+                _ptr(self.ws_u[k]), self.ws_u[k].numel(), self._h[k]))
         a = self.static
         check(self.L.egoprior_render_frame(
             C.byref(cam), C.byref(self.rp), _ptr(a.points), a.capacity, _ptr(a.count), _ptr(a.flags),

@@ -120,8 +120,10 @@ def read_rgb_artifacts(rgb_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
         yield i, np.asarray(arr[i], dtype=np.uint8)
 
 
-def read_depth_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
-    """Yields (frame index, (H,W) float32 metric depth).  EXR channel Z is HALF; a frame that fails to load yields NaN."""
+def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterator[tuple[int, np.ndarray]]:
+    """Yields (frame index, (H,W) float32 metric depth).  EXR channel Z is HALF; a frame that fails to load yields NaN.
+    keep_half: hand float16 data on as float16 (half the upload; the GPU kernels widen it, which is exact) instead of
+    widening it here as vipe/utils/io.py:277 does."""
     zip_file_path = Path(zip_file_path)
     if zip_file_path.exists():
         try:
@@ -145,14 +147,16 @@ def read_depth_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarray]
                         dw = exr.header()["dataWindow"]
                         vw, vh = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
                         buf = exr.channels(["Z"])[0]
-                        yield idx, np.frombuffer(buf, dtype=np.float16).reshape(vh, vw).astype(np.float32)
+                        half = np.frombuffer(buf, dtype=np.float16).reshape(vh, vw)
+                        yield idx, (half.copy() if keep_half else half.astype(np.float32))
             return
     tw = _twin(zip_file_path)
     if not tw.exists():
         raise FileNotFoundError(str(zip_file_path))
     arr = np.load(tw, mmap_mode="r")
     for i in range(arr.shape[0]):
-        yield i, np.asarray(arr[i]).astype(np.float32)
+        a = np.asarray(arr[i])
+        yield i, (a.copy() if (keep_half and a.dtype == np.float16) else a.astype(np.float32))
 
 
 def decode_png_gray(buf: bytes) -> np.ndarray:

@@ -170,7 +170,7 @@ def _frames(artifact: ArtifactPath, tolerant: bool):
     """One sequential pass over (c2w, rgb, intr, camera type, depth, mask) like the reference's zip(...)."""
     _, poses = read_pose_artifacts(artifact.pose_path)
     _, intr, types = read_intrinsics_artifacts(artifact.intrinsics_path, artifact.camera_type_path)
-    depth_it = read_depth_artifacts(artifact.depth_path)
+    depth_it = read_depth_artifacts(artifact.depth_path, keep_half=True)  # uploaded as stored
     mask_it = read_instance_artifacts(artifact.mask_path)
     if tolerant:
         depth_it, mask_it = _none_after_missing(depth_it), _none_after_missing(mask_it)
@@ -438,7 +438,7 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
             c2w, rgb, intr, ct, depth, mask = item
             if depth is not None and mask is not None:
                 _check_pinhole(ct)
-                d = E.to_device(depth, torch.float32)
+                d = E.depth_to_device(depth)
                 dyn_in = (d, E.to_device(rgb, torch.uint8), E.to_device(mask, torch.uint8),
                           _eng.make_unproject_params(d.shape[0], d.shape[1], 2, _lib.SELECT_DYNAMIC, intr, c2w,
                                                      T_cam_to_world))

@@ -87,6 +87,10 @@ int egoprior_abi_version(void);
  * d_depth (H,W) float32 -> d_mask_out (H,W) uint8 (1 = reliable).
  * --------------------------------------------------------------------------------------------------------------- */
 int egoprior_reliable_depth_mask(const float* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out, void* stream);
+/* The *_f16 variants below take the depth map as IEEE float16 bit patterns, the precision the depth artifacts are
+ * stored in (EXR channel Z, pixel type HALF: vipe/utils/io.py:274-312, which widens them to float32 on the host).
+ * Widening on the device is exact, so the results are the same bits; the upload and the HBM footprint halve. */
+int egoprior_reliable_depth_mask_f16(const uint16_t* d_depth, int32_t H, int32_t W, uint8_t* d_mask_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * One exo frame -> compacted points.  Stands in for the per-frame body of build_background_pointcloud (:358-430,
@@ -103,6 +107,9 @@ size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32_t subsampl
 int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
                              const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
                              int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
+int egoprior_unproject_frame_f16(const egoprior_unproject_params* p, const uint16_t* d_depth, const uint8_t* d_rgb,
+                                 const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
+                                 int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Mean background  --  compute_robust_mean_tensors (:459-473) + the frame loop of build_mean_background_pointcloud
@@ -117,6 +124,8 @@ int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_meanbg_state_bytes(int32_t H, int32_t W);
 int egoprior_meanbg_accumulate(float* d_state, const float* d_depth, const uint8_t* d_rgb, const uint8_t* d_mask,
+                               int32_t F, int64_t first_index, int32_t H, int32_t W, void* stream);
+int egoprior_meanbg_accumulate_f16(float* d_state, const uint16_t* d_depth, const uint8_t* d_rgb, const uint8_t* d_mask,
                                int32_t F, int64_t first_index, int32_t H, int32_t W, void* stream);
 int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t W, float* d_mean_depth, uint8_t* d_mean_rgb,
                              void* stream);

@@ -79,6 +79,37 @@ def test_unproject_frame(engine, s, select):
         assert cloud.flags.item() == int(ref_c.size > 0 and ref_c.max() > 1)
 
 
+@pytest.mark.parametrize("s", [1, 2, 3, 5])
+def test_float16_depth_gives_the_same_bits(engine, s):
+    """Depth handed over as float16 (the precision of the EXR artifacts) is widened on the device; masks, points and the
+    mean background must equal what the float32 path gives for the same values, and the oracle's result."""
+    from egoprior import _lib
+    clip = synthetic_clip(120, 208, 6)  # make_frames rounds its depth to float16 values
+    d32 = clip["depth"]
+    d16 = d32.astype(np.float16)
+    assert np.array_equal(d16.astype(F32), d32)
+    m32 = engine.reliable_depth_mask(d32[0])
+    m16 = engine.reliable_depth_mask(d16[0])
+    assert torch.equal(m16, m32)
+    assert np.array_equal(m16.cpu().numpy(), O.reliable_depth_mask_range(d32[0]))
+    for select, name in ((_lib.SELECT_STATIC, "static"), (_lib.SELECT_DYNAMIC, "dynamic")):
+        a = engine.unproject_frame(d32[1], clip["rgb"][1], clip["mask"][1], clip["intr"], clip["c2w"], clip["T"],
+                                   subsample=s, select=select, want_xyz64=True)
+        b = engine.unproject_frame(d16[1], clip["rgb"][1], clip["mask"][1], clip["intr"], clip["c2w"], clip["T"],
+                                   subsample=s, select=select, want_xyz64=True)
+        n = a.n()
+        assert n == b.n() and n > 0
+        assert torch.equal(a.points[:n], b.points[:n]) and torch.equal(a.xyz64[:n], b.xyz64[:n])
+        ref_p, _ = O.unproject_frame(d32[1], clip["rgb"][1], clip["mask"][1], clip["intr"], clip["c2w"], clip["T"], s,
+                                     name)
+        assert np.array_equal(b.xyz64[:n].cpu().numpy(), ref_p)
+    if s == 1:
+        st32, st16 = engine.meanbg_new_state(120, 208), engine.meanbg_new_state(120, 208)
+        engine.meanbg_accumulate(st32, d32, clip["rgb"], clip["mask"], 0)
+        engine.meanbg_accumulate(st16, torch.from_numpy(d16).to(engine.device), clip["rgb"], clip["mask"], 0)
+        assert torch.equal(st16, st32)
+
+
 def test_unproject_without_mask(engine):
     from egoprior import _lib
     clip = synthetic_clip(64, 96, 1)

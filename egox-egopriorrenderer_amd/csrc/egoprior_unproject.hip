@@ -226,6 +226,39 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const DT* __restric
     static_assert(4 * (BX / 4 - 1) * S + 4 * ((3 * S + 5 + 3) / 4) <= TS, "row reads stay inside the tile row");
     __shared__ __align__(16) float tile[TS * FH];
     const int i0 = blockIdx.x * BX, j0 = blockIdx.y * BY;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = i0 + 4 * tx, j = j0 + ty;
+    const int v = j * S;  // image row of the samples; sample k sits at image column (i + k) * S
+    // The instance rule first: which of the thread's samples can be selected at all.  A workgroup none of whose samples
+    // can (typical for the dynamic selection: moving objects cover a small part of the frame) writes zero flags
+    // and skips the depth footprint and the stencil altogether.
+    uint32_t want = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bool w = (j < Hs) && (i + k < Ws);
+        if (w && select != EGOPRIOR_SELECT_ALL) {
+            if (mask != nullptr) {
+                const uint8_t m = mask[(size_t)v * W + (size_t)(i + k) * S];
+                w = (select == EGOPRIOR_SELECT_STATIC) ? (m == 0) : (m != 0);
+            } else {
+                w = select != EGOPRIOR_SELECT_DYNAMIC;
+            }
+        }
+        want |= w ? (1u << k) : 0u;
+    }
+    if (__syncthreads_or(want != 0u) == 0) {
+        if (j < Hs) {
+            const size_t o = (size_t)j * Ws + i;
+            if (i + 3 < Ws && (o & 3) == 0) {
+                *reinterpret_cast<uint32_t*>(&flags[o]) = 0u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i + k < Ws) flags[o + k] = 0;
+            }
+        }
+        return;
+    }
     {
         // all of a thread's footprint loads are issued before the first of them is stored to LDS
         constexpr int NL = (TS * FH + 255) / 256;
@@ -247,26 +280,12 @@ __global__ void __launch_bounds__(256) k_reliable_flags_row4(const DT* __restric
         }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i = i0 + 4 * tx, j = j0 + ty;
-    const int v = j * S;  // image row of the samples; sample k sits at image column (i + k) * S
     float centre[4];
-    const uint32_t okbits = reliable4<S, TS>(tile, tx, ty, i, v, H, W, centre);
+    const uint32_t okbits = reliable4<S, TS>(tile, tx, ty, i, v, H, W, centre) & want;
     if (j >= Hs) return;
     uint32_t packed = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        bool ok = ((okbits >> k) & 1u) != 0u;
-        if (select != EGOPRIOR_SELECT_ALL && (i + k) < Ws) {
-            if (mask != nullptr) {
-                const uint8_t m = mask[(size_t)v * W + (size_t)(i + k) * S];
-                ok = ok && ((select == EGOPRIOR_SELECT_STATIC) ? (m == 0) : (m != 0));
-            } else if (select == EGOPRIOR_SELECT_DYNAMIC) {
-                ok = false;
-            }
-        }
-        packed |= ok ? (1u << (8 * k)) : 0u;
-    }
+    for (int k = 0; k < 4; ++k) packed |= ((okbits >> k) & 1u) << (8 * k);
     const size_t o = (size_t)j * Ws + i;
     if (i + 3 < Ws && (o & 3) == 0) {
         *reinterpret_cast<uint32_t*>(&flags[o]) = packed;

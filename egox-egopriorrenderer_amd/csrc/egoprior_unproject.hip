@@ -334,14 +334,24 @@ __global__ void __launch_bounds__(256) k_reliable_flags_direct(const DT* __restr
 // ------------------------------------------------------------------------------------------------------------------
 #define EP_CB 1024
 
+// the four flag bytes of elements base .. base+3 as one word (byte k = element base+k; zero past n)
+__device__ __forceinline__ uint32_t load_flags4(const uint8_t* __restrict__ flags, int64_t base, int64_t n) {
+    if (base + 3 < n) return *reinterpret_cast<const uint32_t*>(flags + base);  // base is a multiple of 4
+    uint32_t w = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) w |= (uint32_t)flags[base + k] << (8 * k);
+    return w;
+}
+
 __global__ void __launch_bounds__(256) k_flag_block_count(const uint8_t* __restrict__ flags, int64_t n,
                                                           uint32_t* __restrict__ block_count) {
     __shared__ uint32_t ws[4];
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    const uint32_t w4 = load_flags4(flags, base, n);
     uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (base + k < n) c += flags[base + k] ? 1u : 0u;
+    for (int k = 0; k < 4; ++k) c += ((w4 >> (8 * k)) & 255u) ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
@@ -400,9 +410,13 @@ __device__ __forceinline__ uint32_t block_exclusive_base(uint32_t thread_total, 
     return woff + incl - thread_total;
 }
 
+// Must be reached by all threads of the workgroup.  One atomic per workgroup at most, and none once the flag is up:
+// thousands of same-address atomics would serialise in the L2.
 __device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict__ d_flags) {
     if (d_flags == nullptr) return;
-    if (__ballot(any_gt1) != 0ull && (threadIdx.x & 63) == 0) atomicOr(d_flags, 1);
+    if (__syncthreads_or(any_gt1 ? 1 : 0) != 0 && threadIdx.x == 0 &&
+        __atomic_load_n(d_flags, __ATOMIC_RELAXED) == 0)
+        atomicOr(d_flags, 1);
 }
 
 // flags + block offsets -> compacted records: rays * depth, c2w (float32), exo->world (float64), colour bytes
@@ -411,29 +425,53 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
                                                            const DT* __restrict__ depth,
                                                            const uint8_t* __restrict__ rgb,
                                                            const uint8_t* __restrict__ flags,
+                                                           const uint32_t* __restrict__ block_count,
                                                            const uint32_t* __restrict__ block_offset,
                                                            egoprior_point* __restrict__ out,
                                                            double* __restrict__ out64, int32_t* __restrict__ d_flags) {
     __shared__ uint32_t ws[4];
     const int64_t n = (int64_t)Hs * Ws;
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    if (block_count[blockIdx.x] == 0u) return;  // nothing selected in this block (uniform for the workgroup)
+    const uint32_t w4 = load_flags4(flags, base, n);
     bool f[4];
     uint32_t c = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        f[k] = (base + k < n) && (flags[base + k] != 0);
+        f[k] = ((w4 >> (8 * k)) & 255u) != 0u;
         c += f[k] ? 1u : 0u;
+    }
+    // The depth and colour of the selected elements are fetched together (unselected ones read pixel 0) and before the
+    // block-wide scan, so that their latency overlaps it; one division gives the grid position of all four elements.
+    int jj[4], ii[4];
+    {
+        const int64_t eb = base < n ? base : n - 1;
+        jj[0] = (int)(eb / Ws);
+        ii[0] = (int)(eb - (int64_t)jj[0] * Ws);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const bool wrap = ii[k - 1] + 1 == Ws;
+            ii[k] = wrap ? 0 : ii[k - 1] + 1;
+            jj[k] = jj[k - 1] + (wrap ? 1 : 0);
+        }
+    }
+    float dv[4];
+    uint32_t cr[4], cg[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t pix = f[k] ? (size_t)(jj[k] * p.subsample) * p.W + (size_t)(ii[k] * p.subsample) : 0;
+        dv[k] = ldd(depth, pix);
+        cr[k] = rgb[pix * 3 + 0];
+        cg[k] = rgb[pix * 3 + 1];
+        cb[k] = rgb[pix * 3 + 2];
     }
     uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
     bool gt1 = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!f[k]) continue;
-        const int64_t e = base + k;
-        const int j = (int)(e / Ws), i = (int)(e - (int64_t)j * Ws);
-        const int u = i * p.subsample, v = j * p.subsample;
-        const size_t pix = (size_t)v * p.W + u;
-        const float d = ldd(depth, pix);
+        const int u = ii[k] * p.subsample, v = jj[k] * p.subsample;
+        const float d = dv[k];
         const float X = ((float)u - p.cx) / p.fx;
         const float Y = ((float)v - p.cy) / p.fy;
         const float pcx = X * d, pcy = Y * d, pcz = 1.0f * d;
@@ -443,7 +481,7 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
         const double wx = ((p.T[0] * (double)vx + p.T[1] * (double)vy) + p.T[2] * (double)vz) + p.T[3];
         const double wy = ((p.T[4] * (double)vx + p.T[5] * (double)vy) + p.T[6] * (double)vz) + p.T[7];
         const double wz = ((p.T[8] * (double)vx + p.T[9] * (double)vy) + p.T[10] * (double)vz) + p.T[11];
-        const uint32_t r = rgb[pix * 3 + 0], g = rgb[pix * 3 + 1], b = rgb[pix * 3 + 2];
+        const uint32_t r = cr[k], g = cg[k], b = cb[k];
         gt1 |= (r > 1u) || (g > 1u) || (b > 1u);
         egoprior_point q;
         q.x = (float)wx;
@@ -474,16 +512,19 @@ __global__ void __launch_bounds__(256) k_filter_flags(const float* __restrict__ 
 
 __global__ void __launch_bounds__(256) k_filter_scatter(const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
                                                         int64_t n, const uint8_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ block_count,
                                                         const uint32_t* __restrict__ block_offset,
                                                         egoprior_point* __restrict__ out,
                                                         int32_t* __restrict__ d_flags) {
     __shared__ uint32_t ws[4];
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
+    if (block_count[blockIdx.x] == 0u) return;  // nothing selected in this block (uniform for the workgroup)
+    const uint32_t w4 = load_flags4(flags, base, n);
     bool f[4];
     uint32_t c = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        f[k] = (base + k < n) && (flags[base + k] != 0);
+        f[k] = ((w4 >> (8 * k)) & 255u) != 0u;
         c += f[k] ? 1u : 0u;
     }
     uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
@@ -877,7 +918,7 @@ int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, con
     EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
     EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
-                       c.block_offset, d_points, d_xyz64, d_flags);
+                       c.block_count, c.block_offset, d_points, d_xyz64, d_flags);
     return ep_host::check_launch("unproject_frame");
 }
 }  // namespace
@@ -920,7 +961,7 @@ extern "C" int egoprior_filter_cloud(const float* d_xyz, const uint8_t* d_rgb, i
     EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
     EP_LAUNCH("k_filter_scatter", ep::k_filter_scatter, dim3(c.n_blocks), dim3(256), 0, st, d_xyz, d_rgb, N, c.flags,
-                       c.block_offset, d_points, d_flags);
+                       c.block_count, c.block_offset, d_points, d_flags);
     return ep_host::check_launch("filter_cloud");
 }
 

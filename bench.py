@@ -11,7 +11,10 @@ frame loop (scripts/render_vipe_pointcloud.py:1178-1232) with every input alread
     + projection of [static cloud | dynamic points] + tile binning + exact top-20 splat + compositor + uint8 frame.
 The static cloud is built once per clip before the timed region (as the reference does) and its time is reported
 separately.  With N > 1 every rank renders its own K frames (weak scaling, frames are independent); the mean-background
-sums are all-reduced over RCCL during set-up and the finished frames are gathered on rank 0 inside the timed region.
+sums are all-reduced over RCCL during set-up; the finished frames are gathered on rank 0 over RCCL right after the
+timed region and that gather is timed on its own (`gather_ms`), because an RCCL communicator that is alive while the
+frames render costs about a sixth of the rendering rate on this stack (`--gather blocks` keeps it inside).  Barriers
+and the max over ranks go through a gloo group on the host.
 
 Prints ONE JSON line (rank 0).
 """
@@ -49,6 +52,15 @@ def parse():
     ap.add_argument("--skip-cpu", action="store_true", help="skip the host-CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (egoprior_set_option)")
+    ap.add_argument("--gather", choices=["after", "blocks", "end", "none"], default="after",
+                    help="N > 1: how finished frames reach rank 0.  after (default): one RCCL gather after the timed "
+                         "region, timed on its own (gather_ms); the RCCL communicator does not exist while the frames "
+                         "render.  blocks / end: gathered inside the timed region, block by block behind the rendering "
+                         "or once at its end.  none: no process group at all")
+    ap.add_argument("--stream-pick", type=str, default="",
+                    help="experiment: comma-separated indices into 8 freshly created torch streams to use for the "
+                         "pipeline's slots 1..")
+    ap.add_argument("--debug-timing", action="store_true", help="print the phases of the timed region to stderr")
     ap.add_argument("--no-dynamic", action="store_true",
                     help="experiment: render the static cloud only (skips the per-frame dynamic-point kernels)")
     ap.add_argument("--depth-f16", action="store_true",
@@ -61,6 +73,22 @@ def parse():
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: RCCL prints a version banner there.  Everything written to file descriptor 1
+    # until the end goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,10 +98,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # under torchrun the collectives run even with one rank (a rehearsal of the N > 1 path), unless --gather none
+    if world > 1 or ("TORCHELASTIC_RUN_ID" in os.environ and args.gather != "none"):
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # control plane (barriers, max of the times, work counters): gloo on the host.  Data collectives: an RCCL group
+        # that exists only while it is needed -- with an RCCL communicator alive, kernels of different HIP streams
+        # overlap far less on this stack (measured: 5700 -> 4800 frames/s with one rank and no collective in flight).
+        dist.init_process_group(backend="gloo")
+
+    def rccl_group():
+        return dist.new_group(backend="nccl", device_id=dev)
 
     from egoprior import _lib, synth
     from egoprior import engine as eng
@@ -116,10 +151,12 @@ def main():
     t0 = time.time()
     state = E.meanbg_new_state(H, W)
     E.meanbg_accumulate(state, depth, rgb, mask, 0)
+    data_group = None
     if dist is not None:
+        data_group = rccl_group()
         sums, cnt = E.meanbg_export(state)
-        dist.all_reduce(sums)
-        dist.all_reduce(cnt)
+        dist.all_reduce(sums, group=data_group)
+        dist.all_reduce(cnt, group=data_group)
         E.meanbg_import(state, sums, cnt)
     mean_d, mean_c = E.meanbg_finalize(state)
     bg = E.unproject_frame(mean_d, mean_c, None, intr, c2w, T_c2w, subsample=s, select=_lib.SELECT_ALL)
@@ -136,46 +173,93 @@ def main():
     for f in frame_ids:
         R, t = eng.split_w2c(egos[f])
         cams.append(eng.pinhole_camera(R, t, K_ego, He, We))
-    ring = min(max(args.steps, 1), 64)
+    CH = 64  # frames per gather
+    ring = min(-(-max(args.steps, 1) // CH) * CH, 16 * CH)
     frames_out = torch.empty((ring, We, He, 3), dtype=torch.uint8, device=dev)
     # frames are independent: consecutive ones go round-robin to `--streams` HIP streams (egoprior.engine.FramePipeline)
-    pipe = eng.FramePipeline(E, bg, rp, He, We, exo_hw=(H, W), subsample=s, slots=args.streams)
+    extra = None
+    if args.stream_pick:
+        pool = [torch.cuda.Stream(device=dev) for _ in range(8)]
+        extra = [pool[int(v)] for v in args.stream_pick.split(",")]
+        args.streams = len(extra) + 1
+    pipe = eng.FramePipeline(E, bg, rp, He, We, exo_hw=(H, W), subsample=s, slots=args.streams, extra_streams=extra)
     dyn = pipe.dyns[0]
 
-    def step(i, slot=None):
+    def step_inputs(i):
         f = i % Fl
-        if args.no_dynamic:
-            pipe.submit(cams[f], frames_out[i % ring], slot=slot)
-        else:
-            pipe.submit(cams[f], frames_out[i % ring], up=up, depth=depth[f], rgb=rgb[f], mask=mask[f], slot=slot)
+        return {} if args.no_dynamic else dict(up=up, depth=depth[f], rgb=rgb[f], mask=mask[f])
 
-    gather_list = None
+    def step(i, slot=None):
+        pipe.submit(cams[i % Fl], frames_out[i % ring], slot=slot, **step_inputs(i))
+
+    # N > 1: every finished block of CH frames is gathered on rank 0 while the next block renders (the collective runs
+    # on RCCL's own stream, ordered after the block by pipe.join()); all K frames of every rank arrive within the timed
+    # region.
+    gather_bufs = None
     if dist is not None and rank == 0:
-        gather_list = [torch.empty_like(frames_out) for _ in range(world)]
+        gather_bufs = [[torch.empty((CH, We, He, 3), dtype=torch.uint8, device=dev) for _ in range(world)]
+                       for _ in range(2)]
 
     for i in range(args.warmup):
         step(i)
     pipe.join()
+    if dist is not None and args.gather in ("blocks", "end"):
+        # the first gather sets up RCCL's point-to-point channels: keep that out of the timed region
+        dist.gather(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
     torch.cuda.synchronize()
+    if dist is not None and args.gather == "after":
+        dist.destroy_process_group(data_group)  # no RCCL communicator while the frames render
+        data_group = None
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    works = []
     for i in range(args.steps):
-        step(args.warmup + i)
+        # output slot: position in the current block of CH frames, blocks laid out one after the other
+        pipe.submit(cams[(args.warmup + i) % Fl], frames_out[i % ring], **step_inputs(args.warmup + i))
+        if dist is not None and args.gather == "blocks" and ((i + 1) % CH == 0 or i + 1 == args.steps):
+            pipe.join()
+            blk = i // CH
+            lo = (blk * CH) % ring
+            if len(works) >= 2:
+                works[-2].wait()  # its receive buffers are used again now
+            works.append(dist.gather(frames_out[lo:lo + CH], gather_bufs[blk % 2] if rank == 0 else None, dst=0,
+                                     group=data_group, async_op=True))
     t_issue = time.perf_counter() - t0  # host time to queue all steps (the GPU is still working)
     pipe.join()
-    if dist is not None:
-        dist.gather(frames_out, gather_list, dst=0)
+    if dist is not None and args.gather == "end":
+        for lo in range(0, min(args.steps, ring), CH):
+            dist.gather(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
+    for w in works:
+        w.wait()
     torch.cuda.synchronize()
+    t_done = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.debug_timing:
+        print(f"[rank {rank}] issue {1e3 * t_issue:.2f} ms, frames+gathers done {1e3 * t_done:.2f} ms, "
+              f"after barrier {1e3 * elapsed:.2f} ms", file=sys.stderr)
+    gather_ms = None
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if args.gather == "after":
+            # the K frames of every rank go to rank 0 over RCCL now; timed separately and reported as gather_ms
+            data_group = rccl_group()
+            dist.gather(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)  # set-up
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            for lo in range(0, min(args.steps, ring), CH):
+                dist.gather(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gather_ms = 1e3 * (time.perf_counter() - tg)
     assert int(pipe.status.abs().sum().item()) == 0, "tile lists overflowed"
 
     # ---- work accounting (outside the timed region) -----------------------------------------------------------------
@@ -195,7 +279,7 @@ def main():
         n_dyn_sum += per_frame[f][1]
         pts_candidates += n_bg + ns
     if dist is not None:
-        tt = torch.tensor([pts_entering, pts_candidates, n_dyn_sum], dtype=torch.int64, device=dev)
+        tt = torch.tensor([pts_entering, pts_candidates, n_dyn_sum], dtype=torch.int64)
         dist.all_reduce(tt)
         pts_entering, pts_candidates, n_dyn_sum = [int(v) for v in tt.tolist()]
 
@@ -213,7 +297,7 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return None
 
     n_frames_total = args.steps * world
     fps = n_frames_total / elapsed
@@ -275,6 +359,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4),
         "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 4),
+        "gather": args.gather if dist is not None else None,
+        "gather_ms": None if gather_ms is None else round(gather_ms, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -298,9 +384,9 @@ def main():
     }
     if cpu is not None and cpu.get("value"):
         out["gpu_over_cpu"] = round(fps / cpu["value"], 1)
-    print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return json.dumps(out)
 
 
 def cpu_baseline(E, bg, dyn, depth, rgb, mask, intr, c2w, T_c2w, s, cams, egos, frame_ids, K_ego, He, We, point_size,

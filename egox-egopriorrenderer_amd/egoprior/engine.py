@@ -368,7 +368,8 @@ class FramePipeline:
     """
 
     def __init__(self, engine: Engine, static: DeviceCloud, rp: RasterParams, He: int, We: int,
-                 exo_hw: Optional[Sequence[int]] = None, subsample: int = 1, slots: int = 4):
+                 exo_hw: Optional[Sequence[int]] = None, subsample: int = 1, slots: int = 4,
+                 extra_streams: Optional[Sequence["torch.cuda.Stream"]] = None):
         self.E, self.L = engine, engine.L
         self.static, self.rp, self.He, self.We = static, rp, int(He), int(We)
         self.n_slots = max(1, int(slots))
@@ -377,7 +378,13 @@ class FramePipeline:
         with torch.cuda.device(dev):
             self.main = torch.cuda.current_stream()
             # slot 0 runs on the stream that was current at construction; the others get streams of their own
-            self.streams = [self.main] + [torch.cuda.Stream(device=dev) for _ in range(self.n_slots - 1)]
+            # (extra_streams: the caller's choice of streams for slots 1.., e.g. to keep them off a hardware queue that
+            # a communication library's stream already occupies)
+            extra = list(extra_streams) if extra_streams is not None else \
+                [torch.cuda.Stream(device=dev) for _ in range(self.n_slots - 1)]
+            if len(extra) != self.n_slots - 1:
+                raise ValueError("extra_streams must hold slots - 1 streams")
+            self.streams = [self.main] + extra
         self.exo = None
         self.dyn_cap = 0
         self.ws_u = [None] * self.n_slots

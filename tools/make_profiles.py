@@ -20,7 +20,12 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("ep::", "").split("<")[0].strip()
 
 
-stats = next((src / "trace").rglob("*kernel_stats.csv"))
+def newest(paths):
+    """gpurun merges every run's files into the same local directory: keep the most recent one."""
+    return max(paths, key=lambda f: f.stat().st_mtime)
+
+
+stats = newest((src / "trace").rglob("*kernel_stats.csv"))
 shutil.copy(stats, dst / f"{R}_kernel_stats.csv")
 with open(stats, newline="") as fh:
     rows = list(csv.reader(fh))
@@ -34,7 +39,7 @@ with open(dst / f"{R}_kernel_stats_ep.csv", "w", newline="") as fh:
 
 def counters(sub):
     acc = defaultdict(lambda: defaultdict(list))
-    for f in (src / sub).rglob("*counter_collection.csv"):
+    for f in [newest((src / sub).rglob("*counter_collection.csv"))]:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 if "ep::" in row["Kernel_Name"]:

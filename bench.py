@@ -105,6 +105,7 @@ def run(args):
         # control plane (barriers, max of the times, work counters): gloo on the host.  Data collectives: an RCCL group
         # that exists only while it is needed -- with an RCCL communicator alive, kernels of different HIP streams
         # overlap far less on this stack (measured: 5700 -> 4800 frames/s with one rank and no collective in flight).
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the container's host name need not resolve
         dist.init_process_group(backend="gloo")
 
     def rccl_group():

@@ -423,6 +423,7 @@ __device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict
 template <typename DT>
 __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_params p, int Hs, int Ws,
                                                            const DT* __restrict__ depth,
+                                                           const float* __restrict__ rays,
                                                            const uint8_t* __restrict__ rgb,
                                                            const uint8_t* __restrict__ flags,
                                                            const uint32_t* __restrict__ block_count,
@@ -455,12 +456,18 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
             jj[k] = jj[k - 1] + (wrap ? 1 : 0);
         }
     }
-    float dv[4];
+    float dv[4], rx[4], ry[4], rz[4];
     uint32_t cr[4], cg[4], cb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const size_t pix = f[k] ? (size_t)(jj[k] * p.subsample) * p.W + (size_t)(ii[k] * p.subsample) : 0;
         dv[k] = ldd(depth, pix);
+        if (rays != nullptr) {  // ray table of a non-pinhole camera, one ray per sample of the [::s, ::s] grid
+            const size_t e = f[k] ? (size_t)jj[k] * Ws + ii[k] : 0;
+            rx[k] = rays[e * 3 + 0];
+            ry[k] = rays[e * 3 + 1];
+            rz[k] = rays[e * 3 + 2];
+        }
         cr[k] = rgb[pix * 3 + 0];
         cg[k] = rgb[pix * 3 + 1];
         cb[k] = rgb[pix * 3 + 2];
@@ -472,9 +479,10 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
         if (!f[k]) continue;
         const int u = ii[k] * p.subsample, v = jj[k] * p.subsample;
         const float d = dv[k];
-        const float X = ((float)u - p.cx) / p.fx;
-        const float Y = ((float)v - p.cy) / p.fy;
-        const float pcx = X * d, pcy = Y * d, pcz = 1.0f * d;
+        const float X = (rays != nullptr) ? rx[k] : ((float)u - p.cx) / p.fx;
+        const float Y = (rays != nullptr) ? ry[k] : ((float)v - p.cy) / p.fy;
+        const float Z = (rays != nullptr) ? rz[k] : 1.0f;
+        const float pcx = X * d, pcy = Y * d, pcz = Z * d;
         const float vx = ((p.c2w[0] * pcx + p.c2w[1] * pcy) + p.c2w[2] * pcz) + p.c2w[3];
         const float vy = ((p.c2w[4] * pcx + p.c2w[5] * pcy) + p.c2w[6] * pcz) + p.c2w[7];
         const float vz = ((p.c2w[8] * pcx + p.c2w[9] * pcy) + p.c2w[10] * pcz) + p.c2w[11];
@@ -898,7 +906,7 @@ extern "C" size_t egoprior_unproject_workspace_bytes(int32_t H, int32_t W, int32
 
 namespace {
 template <typename DT>
-int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, const uint8_t* d_rgb,
+int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, const float* d_rays, const uint8_t* d_rgb,
                       const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
                       int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (p == nullptr || d_depth == nullptr || d_rgb == nullptr || d_points == nullptr || d_count == nullptr)
@@ -917,7 +925,7 @@ int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, con
     EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
     EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
                        d_flags);
-    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rgb, c.flags,
+    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rays, d_rgb, c.flags,
                        c.block_count, c.block_offset, d_points, d_xyz64, d_flags);
     return ep_host::check_launch("unproject_frame");
 }
@@ -927,15 +935,27 @@ extern "C" int egoprior_unproject_frame(const egoprior_unproject_params* p, cons
                                         const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
                                         int32_t* d_count, int32_t* d_flags, void* d_workspace, size_t workspace_bytes,
                                         void* stream) {
-    return unproject_frame_t(p, d_depth, d_rgb, d_mask, d_points, d_xyz64, d_count, d_flags, d_workspace,
-                             workspace_bytes, stream);
+    return unproject_frame_t(p, d_depth, (const float*)nullptr, d_rgb, d_mask, d_points, d_xyz64, d_count, d_flags,
+                             d_workspace, workspace_bytes, stream);
 }
 extern "C" int egoprior_unproject_frame_f16(const egoprior_unproject_params* p, const uint16_t* d_depth,
                                             const uint8_t* d_rgb, const uint8_t* d_mask, egoprior_point* d_points,
                                             double* d_xyz64, int32_t* d_count, int32_t* d_flags, void* d_workspace,
                                             size_t workspace_bytes, void* stream) {
-    return unproject_frame_t(p, reinterpret_cast<const __half*>(d_depth), d_rgb, d_mask, d_points, d_xyz64, d_count,
-                             d_flags, d_workspace, workspace_bytes, stream);
+    return unproject_frame_t(p, reinterpret_cast<const __half*>(d_depth), (const float*)nullptr, d_rgb, d_mask,
+                             d_points, d_xyz64, d_count, d_flags, d_workspace, workspace_bytes, stream);
+}
+extern "C" int egoprior_unproject_frame_rays(const egoprior_unproject_params* p, const void* d_depth,
+                                             int32_t depth_is_f16, const float* d_rays, const uint8_t* d_rgb,
+                                             const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
+                                             int32_t* d_count, int32_t* d_flags, void* d_workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (d_rays == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "d_rays is NULL");
+    if (depth_is_f16)
+        return unproject_frame_t(p, reinterpret_cast<const __half*>(d_depth), d_rays, d_rgb, d_mask, d_points, d_xyz64,
+                                 d_count, d_flags, d_workspace, workspace_bytes, stream);
+    return unproject_frame_t(p, reinterpret_cast<const float*>(d_depth), d_rays, d_rgb, d_mask, d_points, d_xyz64,
+                             d_count, d_flags, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t egoprior_filter_workspace_bytes(int64_t N) { return N < 0 ? 0 : compact_ws_bytes(N > 0 ? N : 1); }

@@ -57,6 +57,8 @@ SIGNATURES = {
                                            _vp]),
     "egoprior_unproject_frame_f16": (C.c_int, [C.POINTER(UnprojectParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _sz, _vp]),
+    "egoprior_unproject_frame_rays": (C.c_int, [C.POINTER(UnprojectParams), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _vp, _sz, _vp]),
     "egoprior_meanbg_state_bytes": (_sz, [_i32, _i32]),
     "egoprior_meanbg_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "egoprior_meanbg_accumulate_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),

@@ -192,7 +192,9 @@ class Engine:
     # -- R6 / R7 ------------------------------------------------------------------------------------------------------
     def unproject_frame(self, depth, rgb, mask, intr, c2w, T_cam_to_world, subsample: int = 2,
                         select: int = _lib.SELECT_STATIC, out: Optional[DeviceCloud] = None,
-                        want_xyz64: bool = False) -> DeviceCloud:
+                        want_xyz64: bool = False, rays=None) -> DeviceCloud:
+        """rays: (ceil(H/s), ceil(W/s), 3) float32 ray table of a non-pinhole exo camera (egoprior.cameras.ray_table);
+        None = pinhole rays from `intr`."""
         d = self.depth_to_device(depth)
         c = self.to_device(rgb, torch.uint8)
         m = None if mask is None else self.to_device(mask, torch.uint8)
@@ -211,9 +213,18 @@ class Engine:
         nbytes = self.L.egoprior_unproject_workspace_bytes(H, W, s)
         ws = self._workspace("unproject", nbytes)
         with torch.cuda.device(self.device):
-            check(self._by_depth("egoprior_unproject_frame", d)(
-                C.byref(p), _ptr(d), _ptr(c), _ptr(m), _ptr(out.points), _ptr(out.xyz64) if want_xyz64 else None,
-                _ptr(out.count), _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
+            if rays is not None:
+                r = self.to_device(rays, torch.float32)
+                if tuple(r.shape) != ((H + s - 1) // s, (W + s - 1) // s, 3):
+                    raise ValueError("ray table does not match the subsampled frame")
+                check(self.L.egoprior_unproject_frame_rays(
+                    C.byref(p), _ptr(d), int(d.dtype == torch.float16), _ptr(r), _ptr(c), _ptr(m), _ptr(out.points),
+                    _ptr(out.xyz64) if want_xyz64 else None, _ptr(out.count), _ptr(out.flags), _ptr(ws), ws.numel(),
+                    _stream()))
+            else:
+                check(self._by_depth("egoprior_unproject_frame", d)(
+                    C.byref(p), _ptr(d), _ptr(c), _ptr(m), _ptr(out.points), _ptr(out.xyz64) if want_xyz64 else None,
+                    _ptr(out.count), _ptr(out.flags), _ptr(ws), ws.numel(), _stream()))
         return out
 
     # -- render-entry filters -----------------------------------------------------------------------------------------
@@ -419,7 +430,8 @@ class FramePipeline:
 
     def submit(self, cam: Camera, out_image: torch.Tensor, up: Optional[UnprojectParams] = None,
                depth: Optional[torch.Tensor] = None, rgb: Optional[torch.Tensor] = None,
-               mask: Optional[torch.Tensor] = None, slot: Optional[int] = None, after_main: bool = False) -> int:
+               mask: Optional[torch.Tensor] = None, slot: Optional[int] = None, after_main: bool = False,
+               rays: Optional[torch.Tensor] = None) -> int:
         """Queues one frame; returns the slot it went to.  With `up`, `depth`, `rgb` (and `mask`) given, the frame's
         dynamic points are extracted first (same slot, same stream) and rendered together with the static cloud.
         `after_main`: the frame's inputs were produced by work queued on the main stream since the last submit (an
@@ -435,9 +447,9 @@ class FramePipeline:
         with torch.cuda.device(self.E.device):
             if after_main and k > 0:
                 self.streams[k].wait_stream(self.main)
-            return self._submit(k, cam, out_image, up, depth, rgb, mask)
+            return self._submit(k, cam, out_image, up, depth, rgb, mask, rays)
 
-    def _submit(self, k, cam, out_image, up, depth, rgb, mask) -> int:
+    def _submit(self, k, cam, out_image, up, depth, rgb, mask, rays=None) -> int:
         self._fork()
         d = None
         if up is not None:
@@ -453,9 +465,15 @@ class FramePipeline:
             d = self.dyns[k]
             if depth.dtype not in (torch.float32, torch.float16) or not depth.is_contiguous():
                 raise ValueError("depth must be a contiguous float32 or float16 tensor")
-            check(self.E._by_depth("egoprior_unproject_frame", depth)(
-                C.byref(up), _ptr(depth), _ptr(rgb), _ptr(mask), _ptr(d.points), None, _ptr(d.count), _ptr(d.flags),
-                _ptr(self.ws_u[k]), self.ws_u[k].numel(), self._h[k]))
+            if rays is not None:  # device ray table of a non-pinhole exo camera, (ceil(H/s), ceil(W/s), 3) float32
+                check(self.L.egoprior_unproject_frame_rays(
+                    C.byref(up), _ptr(depth), int(depth.dtype == torch.float16), _ptr(rays), _ptr(rgb), _ptr(mask),
+                    _ptr(d.points), None, _ptr(d.count), _ptr(d.flags), _ptr(self.ws_u[k]), self.ws_u[k].numel(),
+                    self._h[k]))
+            else:
+                check(self.E._by_depth("egoprior_unproject_frame", depth)(
+                    C.byref(up), _ptr(depth), _ptr(rgb), _ptr(mask), _ptr(d.points), None, _ptr(d.count),
+                    _ptr(d.flags), _ptr(self.ws_u[k]), self.ws_u[k].numel(), self._h[k]))
         a = self.static
         check(self.L.egoprior_render_frame(
             C.byref(cam), C.byref(self.rp), _ptr(a.points), a.capacity, _ptr(a.count), _ptr(a.flags),

@@ -266,7 +266,8 @@ def encode_png_rgb(img: np.ndarray) -> bytes:
             + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
-def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w, mask_as_png_zip: bool = True):
+def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w, mask_as_png_zip: bool = True,
+                              camera_type: str = "PINHOLE"):
     """Writes a sequence in the ViPE layout using the array twins for rgb and depth (no codec needed) and, by default,
     the reference's zip-of-PNG container for the instance masks.  depth is stored as float16 like the EXR HALF files."""
     base = Path(base)
@@ -286,7 +287,7 @@ def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w
     np.savez(base / "intrinsics" / f"{name}.npz", data=intr, inds=np.arange(Fn))
     with open(base / "intrinsics" / f"{name}_camera.txt", "w") as f:
         for i in range(Fn):
-            f.write(f"{i}: PINHOLE\n")
+            f.write(f"{i}: {camera_type}\n")
     if mask is not None:
         if mask_as_png_zip:
             with zipfile.ZipFile(base / "mask" / f"{name}.zip", "w", zipfile.ZIP_DEFLATED) as z:

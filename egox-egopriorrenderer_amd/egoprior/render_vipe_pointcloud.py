@@ -31,6 +31,7 @@ import numpy as np
 
 from . import _lib
 from . import engine as _eng
+from .cameras import ray_table
 from .io import (ArtifactPath, read_depth_artifacts, read_instance_artifacts, read_intrinsics_artifacts,
                  read_pose_artifacts, read_rgb_artifacts, write_video)
 
@@ -161,9 +162,23 @@ def _none_after_missing(it):
             yield None, None
 
 
-def _check_pinhole(camera_type: str):
-    if camera_type != "PINHOLE":
-        raise NotImplementedError(f"exo camera type {camera_type}: only PINHOLE unprojection runs on the GPU path")
+class _RayTables:
+    """Device ray tables of non-pinhole exo cameras, one per (camera type, intrinsics, frame size, subsample); None for
+    PINHOLE, whose rays the kernel evaluates itself."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, camera_type, intr, H: int, W: int, s: int):
+        ct = str(camera_type).upper()
+        if ct == "PINHOLE":
+            return None
+        key = (ct, np.asarray(intr, dtype=np.float32).tobytes(), int(H), int(W), int(s))
+        if key not in self._cache:
+            import torch
+            tab = ray_table(ct, intr, H, W, s)
+            self._cache[key] = _engine().to_device(tab, torch.float32)
+        return self._cache[key]
 
 
 def _frames(artifact: ArtifactPath, tolerant: bool):
@@ -188,14 +203,17 @@ def build_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray, spat
     E = _engine()
     artifact = _first_artifact(input_dir)
     pts, cols, image_size = [], [], None
+    tables, first = _RayTables(), None
     for c2w, rgb, intr, ct, depth, mask in _frames(artifact, tolerant=True):
         if depth is None:
             continue
-        _check_pinhole(ct)
         if image_size is None:
             image_size = tuple(rgb.shape[:2])
-        cloud = E.unproject_frame(depth, rgb, mask, intr, c2w, T_cam_to_world, subsample=spatial_subsample,
-                                  select=_lib.SELECT_STATIC, want_xyz64=True)
+        if first is None:
+            first = (intr, ct)  # the ray table is built once, from the first usable frame (reference :384)
+        rays = tables.get(first[1], first[0], depth.shape[0], depth.shape[1], spatial_subsample)
+        cloud = E.unproject_frame(depth, rgb, mask, first[0], c2w, T_cam_to_world, subsample=spatial_subsample,
+                                  select=_lib.SELECT_STATIC, want_xyz64=True, rays=rays)
         n = cloud.n()
         pts.append(cloud.xyz64[:n].cpu().numpy())
         cols.append(cloud.to_numpy()[1])
@@ -236,10 +254,10 @@ def build_mean_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray,
         logger.warning("No valid background frames found.")
         return np.empty((0, 3)), np.empty((0, 3)), image_size
     c2w, intr, ct = first
-    _check_pinhole(ct)
     mean_d, mean_c = E.meanbg_finalize(state)
+    rays = _RayTables().get(ct, intr, mean_d.shape[0], mean_d.shape[1], spatial_subsample)
     cloud = E.unproject_frame(mean_d, mean_c, None, intr, c2w, T_cam_to_world, subsample=spatial_subsample,
-                              select=_lib.SELECT_ALL, want_xyz64=True)
+                              select=_lib.SELECT_ALL, want_xyz64=True, rays=rays)
     n = cloud.n()
     return cloud.xyz64[:n].cpu().numpy(), cloud.to_numpy()[1], image_size
 
@@ -254,9 +272,9 @@ def build_dynamic_points_for_frame(artifact_path: ArtifactPath, frame_idx: int, 
             continue
         if depth is None or mask is None:
             return np.empty((0, 3)), np.empty((0, 3))
-        _check_pinhole(ct)
+        rays = _RayTables().get(ct, intr, depth.shape[0], depth.shape[1], spatial_subsample)
         cloud = E.unproject_frame(depth, rgb, mask, intr, c2w, T_cam_to_world, subsample=spatial_subsample,
-                                  select=_lib.SELECT_DYNAMIC, want_xyz64=True)
+                                  select=_lib.SELECT_DYNAMIC, want_xyz64=True, rays=rays)
         n = cloud.n()
         if n == 0:
             return np.empty((0, 3)), np.empty((0, 3))
@@ -388,6 +406,7 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
     bg = _upload(bg_points_3d, bg_colors)  # uploaded and filtered once; the filters are per point
     want_dyn = (not only_bg) and artifact_path is not None and T_cam_to_world is not None
     frames = _frames(artifact_path, tolerant=False) if want_dyn else None
+    tables = _RayTables()
 
     def camera(T_w2c):
         if use_fisheye:
@@ -409,9 +428,9 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
             if item is not None:
                 c2w, rgb, intr, ct, depth, mask = item
                 if depth is not None and mask is not None:
-                    _check_pinhole(ct)
                     dyn = E.unproject_frame(depth, rgb, mask, intr, c2w, T_cam_to_world, subsample=2,
-                                            select=_lib.SELECT_DYNAMIC)
+                                            select=_lib.SELECT_DYNAMIC,
+                                            rays=tables.get(ct, intr, depth.shape[0], depth.shape[1], 2))
             if use_fisheye:
                 img = render_points_fisheye(None, None, T_w2c, ego_intrinsics, W=width, H=height,
                                             point_size=point_size, radial_distortion_coeffs=rad,
@@ -437,11 +456,11 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
         if item is not None:
             c2w, rgb, intr, ct, depth, mask = item
             if depth is not None and mask is not None:
-                _check_pinhole(ct)
                 d = E.depth_to_device(depth)
                 dyn_in = (d, E.to_device(rgb, torch.uint8), E.to_device(mask, torch.uint8),
                           _eng.make_unproject_params(d.shape[0], d.shape[1], 2, _lib.SELECT_DYNAMIC, intr, c2w,
-                                                     T_cam_to_world))
+                                                     T_cam_to_world),
+                          tables.get(ct, intr, d.shape[0], d.shape[1], 2))
         if pipe is None:
             pipe = _eng.FramePipeline(E, bg, rp, height, width,
                                       exo_hw=tuple(dyn_in[0].shape) if dyn_in is not None else None, subsample=2)
@@ -449,7 +468,7 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
         if dyn_in is not None:
             keep.append(dyn_in)
             pipe.submit(cam, images[frame_idx], up=dyn_in[3], depth=dyn_in[0], rgb=dyn_in[1], mask=dyn_in[2],
-                        after_main=True)
+                        after_main=True, rays=dyn_in[4])
         else:
             pipe.submit(cam, images[frame_idx])
         if len(keep) >= 4 * pipe.n_slots:  # bound the device memory held by uploaded frames

@@ -110,6 +110,14 @@ int egoprior_unproject_frame(const egoprior_unproject_params* p, const float* d_
 int egoprior_unproject_frame_f16(const egoprior_unproject_params* p, const uint16_t* d_depth, const uint8_t* d_rgb,
                                  const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
                                  int32_t* d_flags, void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same with a ray table instead of the pinhole formula: d_rays (ceil(H/s), ceil(W/s), 3) float32, one ray per
+ * sample, as scripts/render_vipe_pointcloud.py:384-398 builds it from CameraType.build_camera_model(intr).iproj_disp
+ * for the MEI (vipe/utils/cameras.py:228-250) and PANORAMA (:366-387) exo cameras; points are rays * depth.  fx, fy,
+ * cx, cy of `p` are ignored.  depth_is_f16 selects the depth type (0: float32, 1: float16 bit patterns). */
+int egoprior_unproject_frame_rays(const egoprior_unproject_params* p, const void* d_depth, int32_t depth_is_f16,
+                                  const float* d_rays, const uint8_t* d_rgb, const uint8_t* d_mask,
+                                  egoprior_point* d_points, double* d_xyz64, int32_t* d_count, int32_t* d_flags,
+                                  void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Mean background  --  compute_robust_mean_tensors (:459-473) + the frame loop of build_mean_background_pointcloud

@@ -93,6 +93,41 @@ def pinhole_rays(H: int, W: int, s: int, intr) -> np.ndarray:
     return rays
 
 
+def mei_rays(H: int, W: int, s: int, intr5) -> np.ndarray:
+    """Unified (Mei) camera model, vipe/utils/cameras.py:228-250, on the pixel grid of
+    scripts/render_vipe_pointcloud.py:384-398, followed by the script's division by z (= 1): float32 throughout.
+        u_ = (u - cx) / fx, v_ = (v - cy) / fy, r2 = u_^2 + v_^2, q = sqrt(1 + (1 - k1^2) r2),
+        factor = (k1 + q) / (1 + r2), X = u_ * factor / (factor - k1), Y likewise, Z = 1."""
+    fx, fy, cx, cy, k1 = [F32(v) for v in np.asarray(intr5, dtype=F32)[:5]]
+    v, u = np.meshgrid(np.arange(H, dtype=F32)[::s], np.arange(W, dtype=F32)[::s], indexing="ij")
+    ub = (u - cx) / fx
+    vb = (v - cy) / fy
+    r2 = ub * ub + vb * vb
+    q = np.sqrt(F32(1) + (F32(1) - k1 * k1) * r2)
+    factor = (k1 + q) / (F32(1) + r2)
+    X = ub * factor / (factor - k1)
+    Y = vb * factor / (factor - k1)
+    one = np.ones_like(X)
+    rays = np.stack([X, Y, one], axis=-1).astype(F32)
+    return rays / rays[..., 2:3]
+
+
+def panorama_rays(H: int, W: int, s: int) -> np.ndarray:
+    """Equirectangular model, vipe/utils/cameras.py:366-387, with u, v normalised by (W-1), (H-1) as at
+    scripts/render_vipe_pointcloud.py:391-393; not divided by z.  sin / cos come from the host's libm here and from
+    torch's vectorised kernels in the reference: equal to within an ulp or two, not always bit for bit."""
+    v, u = np.meshgrid(np.arange(H, dtype=F32)[::s], np.arange(W, dtype=F32)[::s], indexing="ij")
+    v = v / F32(H - 1)
+    u = u / F32(W - 1)
+    theta = (u - F32(0.5)) * F32(2) * F32(np.pi)
+    phi = v * F32(np.pi)
+    sp = np.sin(phi).astype(F32)
+    x = sp * np.sin(theta).astype(F32)
+    y = -np.cos(phi).astype(F32)
+    z = sp * np.cos(theta).astype(F32)
+    return np.stack([x, y, z], axis=-1).astype(F32)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # R5: reliability mask
 # --------------------------------------------------------------------------------------------------------------------
@@ -149,16 +184,17 @@ def apply_T_f64(p: np.ndarray, T: np.ndarray) -> np.ndarray:
     return out
 
 
-def unproject_frame(depth, rgb_u8, mask, intr, c2w, T_cam_to_world, s: int = 2, select: str = "static"):
+def unproject_frame(depth, rgb_u8, mask, intr, c2w, T_cam_to_world, s: int = 2, select: str = "static", rays=None):
     """One frame's points: (N,3) float64 world coordinates, (N,3) uint8 colours, row-major over the [::s, ::s] grid.
 
     select="static" keeps mask == 0 (everything when mask is None); "dynamic" keeps mask != 0 (nothing when None).
+    rays: ray table of a non-pinhole exo camera (mei_rays / panorama_rays); the pinhole table from `intr` otherwise.
     """
     depth = np.asarray(depth, dtype=F32)
     H, W = depth.shape
     if select == "dynamic" and mask is None:
         return np.empty((0, 3)), np.empty((0, 3))
-    rays = pinhole_rays(H, W, s, intr)
+    rays = pinhole_rays(H, W, s, intr) if rays is None else np.asarray(rays, dtype=F32)
     with np.errstate(invalid="ignore", over="ignore"):
         p_cam = rays * depth[::s, ::s, None]
         p_vipe = apply_c2w_f32(p_cam, c2w)

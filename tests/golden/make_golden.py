@@ -6,6 +6,8 @@ What is produced and from where:
                            vipe/utils/depth.py (reliable_depth_mask_range), loaded by file path.  depth.py imports
                            vipe.ext.lietorch at module level (needs the compiled CUDA extension); three empty stand-in
                            modules are put in sys.modules for that import only -- nothing from them is called.
+  g3_rays_mei_pano.npz ... ray tables of MeiCameraModel / PanoramaCameraModel.iproj_disp (vipe/utils/cameras.py:228-250,
+                           366-387) on the pixel grid of scripts/render_vipe_pointcloud.py:384-398.
   g2_nanmean.npz ......... torch.nan_to_num(torch.nanmean(x, dim=0)) on CPU, the two calls the reference makes at
                            scripts/render_vipe_pointcloud.py:466-471.
   cameras_cmu_bike08_2.json  camera parameters copied from the reference's example data files
@@ -92,6 +94,28 @@ def make_g1(cameras, depth_mod):
     print("g1: mask true fraction", out["mask"].mean(), out["mask2"].mean())
 
 
+def make_g3(cameras):
+    """Ray tables of the two non-pinhole exo camera models, built the way scripts/render_vipe_pointcloud.py:384-398 does."""
+    out = {}
+    H, W = 20, 28
+    for tag, s, intr in (("mei_a", 1, [14.0, 14.5, 13.6, 9.7, 0.8]), ("mei_b", 2, [11.0, 10.5, 14.0, 10.0, 1.35]),
+                         ("mei_c", 3, [30.0, 30.0, 14.0, 10.0, 0.0])):
+        model = cameras.CameraType.MEI.build_camera_model(torch.tensor(intr, dtype=torch.float32))
+        dv, du = torch.meshgrid(torch.arange(H).float()[::s], torch.arange(W).float()[::s], indexing="ij")
+        pts, _, _ = model.iproj_disp(torch.ones_like(dv), du, dv)
+        rays = pts[..., :3].numpy()
+        rays /= rays[..., 2:3]
+        out[f"{tag}_intr"], out[f"{tag}_s"], out[tag] = np.asarray(intr, np.float32), np.int32(s), rays.astype(np.float32)
+    for tag, s in (("pano_a", 1), ("pano_b", 2)):
+        model = cameras.CameraType.PANORAMA.build_camera_model(torch.zeros(4))
+        dv, du = torch.meshgrid(torch.arange(H).float()[::s], torch.arange(W).float()[::s], indexing="ij")
+        dv, du = dv / (H - 1), du / (W - 1)
+        pts, _, _ = model.iproj_disp(torch.ones_like(dv), du, dv)
+        out[f"{tag}_s"], out[tag] = np.int32(s), pts[..., :3].numpy().astype(np.float32)
+    out["H"], out["W"] = np.int32(H), np.int32(W)
+    np.savez_compressed(OUT / "g3_rays_mei_pano.npz", **out)
+
+
 def make_g2():
     rng = np.random.default_rng(1)
     out = {}
@@ -131,5 +155,6 @@ if __name__ == "__main__":
     cams, dep = load_reference_helpers()
     make_g1(cams, dep)
     make_g2()
+    make_g3(cams)
     make_cameras()
     print("golden fixtures written to", OUT)

@@ -192,3 +192,25 @@ def test_png_decoder_all_filters():
     png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
            + chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b""))
     assert np.array_equal(eio.decode_png_gray(png), img)
+
+
+def test_host_ray_tables_follow_the_reference_camera_models():
+    """egoprior.cameras.ray_table applies the torch operations of the reference's MeiCameraModel / PanoramaCameraModel;
+    against tables those classes produced (G3).  torch's vectorised sqrt / sin / cos may differ in the last bit from one
+    CPU to another, hence the small tolerances."""
+    from pathlib import Path
+    from egoprior.cameras import ray_table
+    g = np.load(Path(__file__).parent / "golden" / "g3_rays_mei_pano.npz")
+    H, W = int(g["H"]), int(g["W"])
+    assert ray_table("PINHOLE", [10, 10, 5, 5], H, W, 2) is None
+    for tag in ("mei_a", "mei_b", "mei_c"):
+        got = ray_table("MEI", g[f"{tag}_intr"], H, W, int(g[f"{tag}_s"]))
+        assert got.dtype == np.float32 and got.flags.c_contiguous
+        assert np.allclose(got, g[tag], rtol=2e-5, atol=0, equal_nan=True), tag
+    for tag in ("pano_a", "pano_b"):
+        got = ray_table("panorama", None, H, W, int(g[f"{tag}_s"]))
+        assert np.abs(got - g[tag]).max() <= 2e-7, tag
+    with pytest.raises(ValueError):
+        ray_table("SIMPLE_DIVISIONAL", [1, 1, 0, 0], H, W, 1)
+    with pytest.raises(ValueError):
+        ray_table("MEI", [1, 1, 0, 0], H, W, 1)

@@ -164,3 +164,41 @@ def test_white_pixel_metrics_match_the_numpy_recipe(engine, tmp_path):
     assert np.array_equal(decode_png_gray((tmp_path / "frame_000003_mask.png").read_bytes()),
                           O.white_pixel_mask(frames[2], 30.0)[1])
     assert (tmp_path / "frame_000005.png").exists() and not (tmp_path / "frame_000006.png").exists()
+
+
+@pytest.mark.parametrize("camera_type", ["MEI", "PANORAMA"])
+def test_non_pinhole_exo_cameras(engine, tmp_path, camera_type):
+    """Exo clips whose camera model is not a pinhole go through a ray table (built on the host with the reference's
+    formulas) instead of the in-kernel pinhole rays: builders and frame loop against the oracle fed the same table."""
+    from egoprior import io as eio, synth
+    from egoprior import render_vipe_pointcloud as rv
+    from egoprior.cameras import ray_table
+    F, H, W = 3, 72, 128
+    d, rgb, m = [t.numpy() for t in synth.make_frames(H, W, range(F), F)]
+    intr = np.array([0.75 * W, 0.75 * W, W / 2, H / 2, 0.6], dtype=F32) if camera_type == "MEI" else np.zeros(4, F32)
+    base = tmp_path / "vipe_results" / "take02"
+    eio.write_synthetic_artifacts(base, "exo", d, rgb, m, intr, np.eye(4, dtype=F32), camera_type=camera_type)
+    exo = synth.exo_w2c()
+    T = np.linalg.inv(exo)
+    rays = ray_table(camera_type, intr, H, W, 2)
+    assert rays.shape == (H // 2, W // 2, 3)
+    # accumulated static cloud
+    res = rv.build_background_pointcloud(str(base), T, spatial_subsample=2)
+    parts = [O.unproject_frame(d[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "static", rays=rays)
+             for f in range(F)]
+    ref_p, ref_c = np.vstack([p for p, _ in parts]), np.vstack([c for _, c in parts])
+    assert res[0].shape == ref_p.shape and np.array_equal(res[0], ref_p) and np.array_equal(res[1], ref_c)
+    # dynamic points of one frame (float16 depth comes straight from the .npy twin)
+    art = next(iter(eio.ArtifactPath.glob_artifacts(base, use_video=True)))
+    dp, dc = rv.build_dynamic_points_for_frame(art, 1, T, spatial_subsample=2)
+    rp_, rc_ = O.unproject_frame(d[1], rgb[1], m[1], intr, np.eye(4, dtype=F32), T, 2, "dynamic", rays=rays)
+    assert np.array_equal(dp, rp_) and np.array_equal(dc, rc_)
+    # frame loop: static + per-frame dynamic points through the pipeline
+    egos = synth.ego_orbit_w2c(F, exo)
+    K_ego = np.array([[60.0, 0, 48.0], [0, 60.0, 40.0], [0, 0, 1]], dtype=F32)
+    frames = rv.project_points_to_image_sequential(ref_p, ref_c, [np.asarray(e, dtype=F32) for e in egos], K_ego,
+                                                   (80, 96), point_size=3.0, artifact_path=art, T_cam_to_world=T)
+    for f in range(F):
+        qp, qc = O.unproject_frame(d[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "dynamic", rays=rays)
+        img = O.render_points_pinhole(np.vstack([ref_p, qp]), np.vstack([ref_c, qc]), K_ego, egos[f], 96, 80, 3.0)
+        assert np.array_equal(frames[f], img), f"frame {f}"

@@ -57,3 +57,22 @@ def test_camera_fixture_values():
     assert len(fx["aria01"]["camera_extrinsics"]) == 128
     prm = fx["online_calibration_line0"]["CameraCalibrations"][0]["Projection"]["Params"]
     assert len(prm) == 15 and abs(prm[0] - 1220.592182729911) < 1e-9
+
+
+def test_mei_and_panorama_ray_tables_match_the_reference_models():
+    """G3: ray tables computed by the reference's own MeiCameraModel / PanoramaCameraModel (vipe/utils/cameras.py) with
+    torch on CPU.  torch's vectorised float32 sqrt, sin and cos are not correctly rounded (they differ from libm in the
+    last bit for ~0.5 % of arguments, and from CPU to CPU), and the Mei formula divides by (factor - k1), which
+    amplifies that bit: the tables are compared to 2e-5 relative (Mei) and 2e-7 absolute (panorama)."""
+    g = np.load(Path(__file__).parent / "golden" / "g3_rays_mei_pano.npz")
+    H, W = int(g["H"]), int(g["W"])
+    for tag in ("mei_a", "mei_b", "mei_c"):
+        with np.errstate(invalid="ignore"):
+            got = O.mei_rays(H, W, int(g[f"{tag}_s"]), g[f"{tag}_intr"])
+        assert got.dtype == np.float32 and got.shape == g[tag].shape
+        assert np.array_equal(np.isnan(got), np.isnan(g[tag])), tag  # k1 > 1: no ray beyond the model's field of view
+        assert np.allclose(got, g[tag], rtol=2e-5, atol=0, equal_nan=True), tag
+    assert np.array_equal(O.mei_rays(H, W, 3, g["mei_c_intr"]), g["mei_c"])  # k1 = 0 reduces to the pinhole table
+    for tag in ("pano_a", "pano_b"):
+        got = O.panorama_rays(H, W, int(g[f"{tag}_s"]))
+        assert got.shape == g[tag].shape and np.abs(got - g[tag]).max() <= 2e-7, tag

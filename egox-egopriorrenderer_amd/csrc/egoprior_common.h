@@ -55,9 +55,4 @@ __device__ __forceinline__ bool tile_range(const RasterGeom& g, float px, float 
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (EP_WAVE - 1)); }
 
-// number of set bits of `m` strictly below this lane
-__device__ __forceinline__ int lanes_below(unsigned long long m) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
 }  // namespace ep

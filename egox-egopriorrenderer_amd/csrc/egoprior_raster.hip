@@ -540,18 +540,23 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
 // entries (C/64 per lane, held in registers while the chunk is organised):
 //   load    : C/64 independent, fully coalesced 16-byte record loads per lane (the tile lists hold index, depth
-//             bits and NDC x, y); records whose key cannot beat the current K-th key of any pixel are dropped
-//   sort    : monotone two-level radix bucketing of the keys into LDS (histogram, scan, scatter: O(n)); buckets hold
-//             one or two records each, and every record then ranks itself inside its bucket by counting the smaller
-//             keys there and moves to start + rank.  If some bucket is long (many equal depths) the whole chunk is
-//             bitonic-sorted instead.  Either way S[] ends up sorted.
-//   sweep   : the sorted records are offered front to back, 64 at a time, to all 64 pixels in a branch-free loop
-//             (record coordinates come from v_readlane, i.e. scalar operands) that builds each pixel's 64-bit hit
-//             mask; every lane then appends its hits to its slot list.  Sorted input makes the first K hits of a
-//             pixel its K nearest, so the sweep stops as soon as every pixel holds K.
+//             bits and NDC x, y); records whose key cannot beat the largest K-th key of the tile's pixels (T) are
+//             dropped, which removes about half of every chunk after the first
+//   sort    : a monotone two-level bucket map sends the keys to LDS in O(n).  Level 1 cuts the chunk's key range
+//             into NB equal ranges and histograms them; a range holding c records is cut again into 2^floor(log2 c)
+//             sub-ranges, so buckets hold a record or two unless depths repeat.  (SAMPLED builds take 64 sorted
+//             sample keys as level-1 splitters instead.)  After the scatter every record ranks itself inside its
+//             bucket: short buckets by reading their neighbours' keys, medium ones (up to EP_RANK_WAVE) with a
+//             wave-wide all-pairs count, and a chunk with a longer bucket is bitonic-sorted.  S[] ends up sorted.
+//   sweep   : the sorted records are offered front to back, 64 at a time, to the 64 pixels.  With many open pixels
+//             each lane walks the 64 records (LDS broadcast reads) and shifts one hit bit per record into its
+//             mask; with few open pixels the roles swap: each lane holds one record, the open pixels' coordinates
+//             come from v_readlane and a ballot is the pixel's mask.  Hits are appended to the pixel's slot list two
+//             per trip.  Sorted input makes the first K hits of a pixel its K nearest, so a pixel closes at K hits
+//             (and, from the second chunk on, at the first record beyond its own K-th key).
 //   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
-//             later chunks: compare-exchange insertion).
-// LDS per wave = C*16 (sorted records) + NB*4 (buckets) + K*64*2 (slots).
+//             later chunks: a fixed bitonic merge network over the two sorted lists).
+// LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space).
 // DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
 // the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
 template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false>
@@ -614,17 +619,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             val[u] = e < end;
             rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
         }
-#ifdef EP_DBG_DOUBLE_LOAD
-        // diagnostic: wait for the records, then fetch them a second time (now cache-resident) and keep both alive
-#pragma unroll
-        for (int u = 0; u < RPL; ++u) asm volatile("" ::"v"(rec[u].x));
-#pragma unroll
-        for (int u = 0; u < RPL; ++u) {
-            const uint32_t e = pos + (uint32_t)(u * 64 + lane);
-            const uint4 r2_ = list[val[u] ? e : end - 1u];
-            asm volatile("" ::"v"(r2_.x), "v"(r2_.y), "v"(r2_.z), "v"(r2_.w));
-        }
-#endif
         u64 kmin = ~0ull, kmax = 0ull;
         int m = 0;
 #pragma unroll

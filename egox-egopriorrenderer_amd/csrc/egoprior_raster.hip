@@ -559,7 +559,13 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space).
 // DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
 // the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
-template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false>
+// Value of lane K of the caller's row of 16 lanes.  The compiler folds the move into the instruction that uses it.
+template <int K>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
+}
+
+template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false, bool ROWBCAST = true>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -592,7 +598,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     float2v pxy;
     pxy.x = xf;
     pxy.y = yf;
-
     uint32_t kz[EP_K], ki[EP_K];
 #pragma unroll
     for (int k = 0; k < EP_K; ++k) {
@@ -1000,6 +1005,38 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     hm_lo = (lane == p) ? (uint32_t)hit : hm_lo;
                     hm_hi = (lane == p) ? (uint32_t)(hit >> 32) : hm_hi;
                 }
+            } else if (ROWBCAST) {
+                // Sixteen records at a time sit one per lane in every row of 16 lanes; a record's coordinates reach the
+                // other lanes of the row as the broadcast operand of the subtraction itself (DPP row broadcast), so the
+                // inner loop reads no LDS at all.  Two records share each packed multiply / add / subtract of r2.
+#pragma unroll
+                for (int h = 1; h >= 0; --h) {  // records go in last to first, 32 per mask word
+                    uint32_t bits = 0u;
+                    float2v r2v;
+                    r2v.x = r2;
+                    r2v.y = r2;
+#pragma unroll
+                    for (int g16 = 1; g16 >= 0; --g16) {
+                        const float2v rxy = *reinterpret_cast<const float2v*>(&S[j0 + h * 32 + g16 * 16 + (lane & 15)].z);
+#define EP_PAIR(A_)                                                                                \
+    {                                                                                              \
+        float2v dx, dy;                                                                            \
+        dx.x = row_bcast<A_>(rxy.x) - xf;                                                          \
+        dx.y = row_bcast<A_ + 1>(rxy.x) - xf;                                                      \
+        dy.x = row_bcast<A_>(rxy.y) - yf;                                                          \
+        dy.y = row_bcast<A_ + 1>(rxy.y) - yf;                                                      \
+        const float2v tt = (dx * dx + dy * dy) - r2v;                                              \
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tt.y), 31);                         \
+        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tt.x), 31);                         \
+    }
+                        EP_PAIR(14) EP_PAIR(12) EP_PAIR(10) EP_PAIR(8) EP_PAIR(6) EP_PAIR(4) EP_PAIR(2) EP_PAIR(0)
+#undef EP_PAIR
+                    }
+                    if (h == 0)
+                        hm_lo = bits;
+                    else
+                        hm_hi = bits;
+                }
             } else
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {  // 16 records per group: all LDS reads first, then the arithmetic
@@ -1293,8 +1330,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         case 3:  // larger chunks: faster for a frame on its own, slower with several frames in flight
             EP_SWEEP(1024, 1024, 2);
             break;
-        case 4:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 40>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
+        case 4:  // record coordinates as LDS broadcast reads instead of DPP row broadcasts (kept for comparison)
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 5:

@@ -73,6 +73,9 @@ def parse():
 
 def main():
     args = parse()
+    if args.debug_timing:  # a hung run names the line it hangs on
+        import faulthandler
+        faulthandler.dump_traceback_later(40, exit=True)
     # Only the JSON line may reach stdout: RCCL prints a version banner there.  Everything written to file descriptor 1
     # until the end goes to stderr instead.
     sys.stdout.flush()

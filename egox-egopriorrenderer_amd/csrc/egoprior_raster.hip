@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if (cs == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
             continue;
         }
-#ifdef EP_TILE_TIMES
+#ifdef EP_CHUNK_STATS
         if (lane == 0) {
             atomicAdd(&g_chunk_stats[0], 1u);                          // chunks loaded
             atomicAdd(&g_chunk_stats[1], (uint32_t)(chunk_no > 0));    // ... after the first

@@ -37,7 +37,8 @@ E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
 cs(cbuf, 0)
 c = list(cbuf)
-print(f"chunks {c[0]} (records kept {c[3]}); later chunks {c[1]} (kept {c[4]}), of those unfiltered {c[2]} (kept {c[5]})")
+if c[0]:  # only a build with -DEP_CHUNK_STATS counts these (its atomics distort the wave durations below)
+    print(f"chunks {c[0]} (records kept {c[3]}); later chunks {c[1]} (kept {c[4]}), of those unfiltered {c[2]} (kept {c[5]})")
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()
 assert dbg(buf, 4 * n_tiles) == 0

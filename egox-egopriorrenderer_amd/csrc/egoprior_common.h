@@ -32,8 +32,10 @@ struct RasterGeom {
     float radius2;                     // float32(r) * float32(r)
 };
 
-// Conservative tile rectangle [tx0,tx1] x [ty0,ty1] touched by a disc; false when it misses the image (also for
-// non-finite coordinates and z < 0, which pytorch3d's rasterizer skips).
+// Tile rectangle [tx0,tx1] x [ty0,ty1] of the pixels whose centres can lie inside a disc; false when there is none (the
+// disc misses the image or falls between pixel centres; also for non-finite coordinates and z < 0, which pytorch3d's
+// rasterizer skips).  cx, cy are the disc centre in pixel-index units (pixel i has its centre at i), rad_px carries a
+// margin far above the rounding of that conversion, so the candidates are the pixel indices in [ceil(lo), floor(hi)].
 __device__ __forceinline__ bool tile_range(const RasterGeom& g, float px, float py, float pz, int& tx0, int& tx1,
                                            int& ty0, int& ty1) {
     if (!(pz >= 0.0f)) return false;
@@ -42,10 +44,11 @@ __device__ __forceinline__ bool tile_range(const RasterGeom& g, float px, float 
     const float lox = cx - g.rad_px_x, hix = cx + g.rad_px_x;
     const float loy = cy - g.rad_px_y, hiy = cy + g.rad_px_y;
     if (!(hix >= 0.0f) || !(lox <= (float)(g.W - 1)) || !(hiy >= 0.0f) || !(loy <= (float)(g.H - 1))) return false;
-    const int x0 = (int)floorf(fmaxf(lox, 0.0f));
+    const int x0 = (int)ceilf(fmaxf(lox, 0.0f));
     const int x1 = (int)floorf(fminf(hix, (float)(g.W - 1)));
-    const int y0 = (int)floorf(fmaxf(loy, 0.0f));
+    const int y0 = (int)ceilf(fmaxf(loy, 0.0f));
     const int y1 = (int)floorf(fminf(hiy, (float)(g.H - 1)));
+    if (x0 > x1 || y0 > y1) return false;
     tx0 = x0 / EP_TILE;
     tx1 = x1 / EP_TILE;
     ty0 = y0 / EP_TILE;

@@ -64,5 +64,10 @@ if sq:
     with open(dst / f"{R}_pmc_sq.txt", "w") as fh:
         for k, d in sorted(sq.items()):
             fh.write(f"{k:28s} " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(d.items())) + "\n")
+lds = counters("pmc_lds") if (src / "pmc_lds").exists() else {}
+if lds:
+    with open(dst / f"{R}_pmc_lds.txt", "w") as fh:
+        for k, d in sorted(lds.items()):
+            fh.write(f"{k:28s} " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(d.items())) + "\n")
 json.dump(out, open(dst / "pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if not k.startswith("_") and not k.endswith("KiB")}, indent=1))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round: kernel-trace stats of the default bench command and two PMC passes
-# (HBM read / write bytes).  Run on the GPU box: bash tools/profile_round.sh r01
+# (HBM read / write bytes), an SQ instruction / wait pass and an LDS pass.  Run on the GPU box: bash tools/profile_round.sh r01
 set -e
 R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -11,4 +11,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu --streams 1 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu --streams 1 > $OUT/pmc_write.log 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu --streams 1 > $OUT/pmc_sq.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_lds -- python3 bench.py --frames 16 --steps 8 --warmup 2 --skip-cpu --streams 1 > $OUT/pmc_lds.log 2>&1
 find $OUT -name "*.csv" | head -20

@@ -598,6 +598,16 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     float2v pxy;
     pxy.x = xf;
     pxy.y = yf;
+    // The binning works on tile rectangles, so a list also holds discs that overlap the rectangle's corner tile without
+    // reaching any of its pixel centres.  They are dropped at load time: [cx_lo, cx_hi] x [cy_lo, cy_hi] is the box of the
+    // tile's pixel centres, a disc whose centre is farther than r from it cannot hit (the margin on r^2 is far above the
+    // rounding of either evaluation, so nothing that the exact test would accept is dropped).
+    const float cx_hi = pix_to_ndc(g.W - 1 - txi * EP_TILE, g.W, g.H);
+    const float cx_lo = pix_to_ndc(g.W - 1 - (txi * EP_TILE + EP_TILE - 1), g.W, g.H);
+    const float cy_hi = pix_to_ndc(g.H - 1 - tyi * EP_TILE, g.H, g.W);
+    const float cy_lo = pix_to_ndc(g.H - 1 - (tyi * EP_TILE + EP_TILE - 1), g.H, g.W);
+    const float r2_reach = r2 * 1.0001f;
+
     uint32_t kz[EP_K], ki[EP_K];
 #pragma unroll
     for (int k = 0; k < EP_K; ++k) {
@@ -629,7 +639,9 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
             const u64 key = make_key(rec[u].y, rec[u].x);
-            val[u] = val[u] && (key < T);
+            const float px = __uint_as_float(rec[u].z), py = __uint_as_float(rec[u].w);
+            const float ox = fmaxf(fmaxf(cx_lo - px, px - cx_hi), 0.0f), oy = fmaxf(fmaxf(cy_lo - py, py - cy_hi), 0.0f);
+            val[u] = val[u] && (key < T) && !(ox * ox + oy * oy > r2_reach);
             if (val[u]) {
                 kmin = key < kmin ? key : kmin;
                 kmax = key > kmax ? key : kmax;

@@ -65,6 +65,9 @@ def parse():
                     help="experiment: render the static cloud only (skips the per-frame dynamic-point kernels)")
     ap.add_argument("--depth-f16", action="store_true",
                     help="keep the exo depth maps in HBM as float16 (the precision of the EXR artifacts) instead of float32")
+    ap.add_argument("--fisheye", action="store_true",
+                    help="BASELINE configs[3] instead of configs[1]: fisheye ego camera (the preset Ego-Exo4D radial / "
+                         "tangential / thin-prism coefficients), not rotated; combine with --point-size 10 or 20")
     ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight: consecutive frames go round-robin to this many HIP streams, each with its "
                          "own dynamic-point buffer and workspaces (frames are independent of one another)")
@@ -172,14 +175,21 @@ def run(args):
     # ---- per-frame arguments, prepared once -------------------------------------------------------------------------
     ns = ((H + s - 1) // s) * ((W + s - 1) // s)
     up = eng.make_unproject_params(H, W, s, _lib.SELECT_DYNAMIC, intr, c2w, T_c2w)
-    rp = eng.make_raster_params(args.point_size, He, We, K=20, rotate_cw=True, colors_gt1=-1)
+    rp = eng.make_raster_params(args.point_size, He, We, K=20, rotate_cw=not args.fisheye, colors_gt1=-1)
     cams = []
+    if args.fisheye:
+        from egoprior.render_vipe_pointcloud import load_aria_distortion_coeffs
+        radial, tangential, thin_prism, _, _ = load_aria_distortion_coeffs(None)
     for f in frame_ids:
         R, t = eng.split_w2c(egos[f])
-        cams.append(eng.pinhole_camera(R, t, K_ego, He, We))
+        if args.fisheye:  # scripts/render_vipe_pointcloud.py:1040-1062 with the ego intrinsics of the meta file
+            cams.append(eng.fisheye_camera(R, t, K_ego[0, 0], K_ego[0, 2], K_ego[1, 2], radial, tangential, thin_prism,
+                                           He, We))
+        else:
+            cams.append(eng.pinhole_camera(R, t, K_ego, He, We))
     CH = 64  # frames per gather
     ring = min(-(-max(args.steps, 1) // CH) * CH, 16 * CH)
-    frames_out = torch.empty((ring, We, He, 3), dtype=torch.uint8, device=dev)
+    frames_out = torch.empty((ring, He, We, 3) if args.fisheye else (ring, We, He, 3), dtype=torch.uint8, device=dev)
     # frames are independent: consecutive ones go round-robin to `--streams` HIP streams (egoprior.engine.FramePipeline)
     extra = None
     if args.stream_pick:
@@ -304,6 +314,7 @@ def run(args):
         return None
 
     n_frames_total = args.steps * world
+    cam_kind = "fisheye" if args.fisheye else "pinhole"
     fps = n_frames_total / elapsed
     n_avg = pts_entering / n_frames_total  # points entering the binning stage per frame
     n_in_avg = n_bg + n_dyn_sum / n_frames_total
@@ -355,7 +366,7 @@ def run(args):
                            args.point_size, args.cpu_seconds)
 
     out = {
-        "metric": "ego-prior frames/sec (1080p exo -> 480x832 pinhole ego, points_per_pixel 20)",
+        "metric": f"ego-prior frames/sec (1080p exo -> 480x832 {cam_kind} ego, points_per_pixel 20)",
         "value": round(fps, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -370,8 +381,8 @@ def run(args):
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {W}x{H} exo depth+RGB+mask, subsample {s}, mean-bg static cloud "
-                               f"({n_bg} pts) + per-frame dynamic points -> {He}x{We} pinhole ego, point_size "
+        "config": {"workload": f"BASELINE configs[{3 if args.fisheye else 1}]: {W}x{H} exo depth+RGB+mask, subsample {s}, mean-bg static cloud "
+                               f"({n_bg} pts) + per-frame dynamic points -> {He}x{We} {cam_kind} ego, point_size "
                                f"{args.point_size}, K=20, {Fl} exo frames/rank resident in HBM",
                    "exo": [H, W], "ego": [He, We], "point_size": args.point_size, "subsample": s, "depth_dtype": "f16" if args.depth_f16 else "f32",
                    "frames_per_rank": Fl, "static_points": n_bg, "frames_in_flight": pipe.n_slots,

@@ -344,9 +344,12 @@ __device__ __forceinline__ uint32_t load_flags4(const uint8_t* __restrict__ flag
     return w;
 }
 
+// d_flags (may be NULL): cleared here when no k_block_scan runs in between (see block_offset_of)
 __global__ void __launch_bounds__(256) k_flag_block_count(const uint8_t* __restrict__ flags, int64_t n,
-                                                          uint32_t* __restrict__ block_count) {
+                                                          uint32_t* __restrict__ block_count,
+                                                          int32_t* __restrict__ d_flags) {
     __shared__ uint32_t ws[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d_flags != nullptr) *d_flags = 0;
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
     const uint32_t w4 = load_flags4(flags, base, n);
     uint32_t c = 0;
@@ -410,6 +413,27 @@ __device__ __forceinline__ uint32_t block_exclusive_base(uint32_t thread_total, 
     return woff + incl - thread_total;
 }
 
+#define EP_FUSED_SCAN_MAX 4096  // up to this many blocks every scatter workgroup sums the counts before it by itself
+
+// Offset of this workgroup's first output record.  With block_offset == NULL (no k_block_scan ran) the workgroup adds up
+// the counts of the blocks before it -- a few KiB that sit in the L2 -- and the last workgroup also publishes the total;
+// one launch less on a chain of four short kernels.  Must be reached by all 256 threads.
+__device__ __forceinline__ uint32_t block_offset_of(const uint32_t* __restrict__ block_count,
+                                                    const uint32_t* __restrict__ block_offset,
+                                                    int32_t* __restrict__ d_count, uint32_t* ws /*[4] shared*/) {
+    if (block_offset != nullptr) return block_offset[blockIdx.x];
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) s += block_count[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const uint32_t before = ws[0] + ws[1] + ws[2] + ws[3];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && d_count != nullptr)
+        *d_count = (int32_t)(before + block_count[blockIdx.x]);
+    return before;
+}
+
 // Must be reached by all threads of the workgroup.  One atomic per workgroup at most, and none once the flag is up:
 // thousands of same-address atomics would serialise in the L2.
 __device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict__ d_flags) {
@@ -429,11 +453,14 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
                                                            const uint32_t* __restrict__ block_count,
                                                            const uint32_t* __restrict__ block_offset,
                                                            egoprior_point* __restrict__ out,
-                                                           double* __restrict__ out64, int32_t* __restrict__ d_flags) {
+                                                           double* __restrict__ out64, int32_t* __restrict__ d_count,
+                                                           int32_t* __restrict__ d_flags) {
     __shared__ uint32_t ws[4];
+    __shared__ uint32_t ws_off[4];
     const int64_t n = (int64_t)Hs * Ws;
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
-    if (block_count[blockIdx.x] == 0u) return;  // nothing selected in this block (uniform for the workgroup)
+    // nothing selected in this block (uniform for the workgroup); the last one may still have the total to publish
+    if (block_count[blockIdx.x] == 0u && !(block_offset == nullptr && blockIdx.x == gridDim.x - 1)) return;
     const uint32_t w4 = load_flags4(flags, base, n);
     bool f[4];
     uint32_t c = 0;
@@ -472,7 +499,7 @@ __global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_pa
         cg[k] = rgb[pix * 3 + 1];
         cb[k] = rgb[pix * 3 + 2];
     }
-    uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
+    uint32_t slot = block_offset_of(block_count, block_offset, d_count, ws_off) + block_exclusive_base(c, ws);
     bool gt1 = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -522,11 +549,13 @@ __global__ void __launch_bounds__(256) k_filter_scatter(const float* __restrict_
                                                         int64_t n, const uint8_t* __restrict__ flags,
                                                         const uint32_t* __restrict__ block_count,
                                                         const uint32_t* __restrict__ block_offset,
-                                                        egoprior_point* __restrict__ out,
+                                                        egoprior_point* __restrict__ out, int32_t* __restrict__ d_count,
                                                         int32_t* __restrict__ d_flags) {
     __shared__ uint32_t ws[4];
+    __shared__ uint32_t ws_off[4];
     const int64_t base = (int64_t)blockIdx.x * EP_CB + (int64_t)threadIdx.x * 4;
-    if (block_count[blockIdx.x] == 0u) return;  // nothing selected in this block (uniform for the workgroup)
+    // nothing selected in this block (uniform for the workgroup); the last one may still have the total to publish
+    if (block_count[blockIdx.x] == 0u && !(block_offset == nullptr && blockIdx.x == gridDim.x - 1)) return;
     const uint32_t w4 = load_flags4(flags, base, n);
     bool f[4];
     uint32_t c = 0;
@@ -535,7 +564,7 @@ __global__ void __launch_bounds__(256) k_filter_scatter(const float* __restrict_
         f[k] = ((w4 >> (8 * k)) & 255u) != 0u;
         c += f[k] ? 1u : 0u;
     }
-    uint32_t slot = block_offset[blockIdx.x] + block_exclusive_base(c, ws);
+    uint32_t slot = block_offset_of(block_count, block_offset, d_count, ws_off) + block_exclusive_base(c, ws);
     bool gt1 = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -922,11 +951,15 @@ int unproject_frame_t(const egoprior_unproject_params* p, const DT* d_depth, con
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "unproject workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (int e = launch_flags(d_depth, d_mask, p->H, p->W, s, p->select, c.flags, st)) return e;
-    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count);
-    EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
-                       d_flags);
-    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth, d_rays, d_rgb, c.flags,
-                       c.block_count, c.block_offset, d_points, d_xyz64, d_flags);
+    const bool fused = c.n_blocks <= EP_FUSED_SCAN_MAX;  // the scatter kernel sums the block counts itself
+    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, n, c.block_count,
+              fused ? d_flags : (int32_t*)nullptr);
+    if (!fused)
+        EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks,
+                  d_count, d_flags);
+    EP_LAUNCH("k_unproject_scatter", ep::k_unproject_scatter<DT>, dim3(c.n_blocks), dim3(256), 0, st, *p, Hs, Ws, d_depth,
+              d_rays, d_rgb, c.flags, c.block_count, fused ? (const uint32_t*)nullptr : c.block_offset, d_points, d_xyz64,
+              d_count, d_flags);
     return ep_host::check_launch("unproject_frame");
 }
 }  // namespace
@@ -977,11 +1010,14 @@ extern "C" int egoprior_filter_cloud(const float* d_xyz, const uint8_t* d_rgb, i
         return ep_host::check_launch("filter_cloud");
     }
     EP_LAUNCH("k_filter_flags", ep::k_filter_flags, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_xyz, N, c.flags);
-    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, N, c.block_count);
-    EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks, d_count,
-                       d_flags);
+    const bool fused = c.n_blocks <= EP_FUSED_SCAN_MAX;
+    EP_LAUNCH("k_flag_block_count", ep::k_flag_block_count, dim3(c.n_blocks), dim3(256), 0, st, c.flags, N, c.block_count,
+              fused ? d_flags : (int32_t*)nullptr);
+    if (!fused)
+        EP_LAUNCH("k_block_scan", ep::k_block_scan, dim3(1), dim3(1024), 0, st, c.block_count, c.block_offset, c.n_blocks,
+                  d_count, d_flags);
     EP_LAUNCH("k_filter_scatter", ep::k_filter_scatter, dim3(c.n_blocks), dim3(256), 0, st, d_xyz, d_rgb, N, c.flags,
-                       c.block_count, c.block_offset, d_points, d_flags);
+              c.block_count, fused ? (const uint32_t*)nullptr : c.block_offset, d_points, d_count, d_flags);
     return ep_host::check_launch("filter_cloud");
 }
 

@@ -65,6 +65,9 @@ def parse():
                     help="experiment: render the static cloud only (skips the per-frame dynamic-point kernels)")
     ap.add_argument("--depth-f16", action="store_true",
                     help="keep the exo depth maps in HBM as float16 (the precision of the EXR artifacts) instead of float32")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 control flow on a box with ONE GPU: every rank uses cuda:0 and the data "
+                         "collectives go through gloo (RCCL refuses two ranks on one device); the numbers mean nothing")
     ap.add_argument("--fisheye", action="store_true",
                     help="BASELINE configs[3] instead of configs[1]: fisheye ego camera (the preset Ego-Exo4D radial / "
                          "tangential / thin-prism coefficients), not rotated; combine with --point-size 10 or 20")
@@ -101,6 +104,8 @@ def run(args):
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -115,7 +120,25 @@ def run(args):
         dist.init_process_group(backend="gloo")
 
     def rccl_group():
+        if args.rehearse_one_gpu:
+            return dist.new_group(backend="gloo")
         return dist.new_group(backend="nccl", device_id=dev)
+
+    def gather_to_rank0(t, bufs, group, async_op=False):
+        """dist.gather of a block of finished frames; in the one-GPU rehearsal through host copies (gloo has no gather
+        for device tensors)."""
+        if not args.rehearse_one_gpu:
+            return dist.gather(t, bufs, dst=0, group=group, async_op=async_op)
+        host = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)] if rank == 0 else None
+        dist.gather(t.cpu(), host, dst=0, group=group)
+        if rank == 0:
+            for b, h in zip(bufs, host):
+                b.copy_(h)
+
+        class _Done:
+            def wait(self):
+                return True
+        return _Done()
 
     from egoprior import _lib, synth
     from egoprior import engine as eng
@@ -219,7 +242,7 @@ def run(args):
     pipe.join()
     if dist is not None and args.gather in ("blocks", "end"):
         # the first gather sets up RCCL's point-to-point channels: keep that out of the timed region
-        dist.gather(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
+        gather_to_rank0(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, data_group)
     torch.cuda.synchronize()
     if dist is not None and args.gather == "after":
         dist.destroy_process_group(data_group)  # no RCCL communicator while the frames render
@@ -239,13 +262,12 @@ def run(args):
             lo = (blk * CH) % ring
             if len(works) >= 2:
                 works[-2].wait()  # its receive buffers are used again now
-            works.append(dist.gather(frames_out[lo:lo + CH], gather_bufs[blk % 2] if rank == 0 else None, dst=0,
-                                     group=data_group, async_op=True))
+            works.append(gather_to_rank0(frames_out[lo:lo + CH], gather_bufs[blk % 2] if rank == 0 else None, data_group, async_op=True))
     t_issue = time.perf_counter() - t0  # host time to queue all steps (the GPU is still working)
     pipe.join()
     if dist is not None and args.gather == "end":
         for lo in range(0, min(args.steps, ring), CH):
-            dist.gather(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
+            gather_to_rank0(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, data_group)
     for w in works:
         w.wait()
     torch.cuda.synchronize()
@@ -265,12 +287,12 @@ def run(args):
         if args.gather == "after":
             # the K frames of every rank go to rank 0 over RCCL now; timed separately and reported as gather_ms
             data_group = rccl_group()
-            dist.gather(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)  # set-up
+            gather_to_rank0(frames_out[0:CH], gather_bufs[0] if rank == 0 else None, data_group)  # set-up
             torch.cuda.synchronize()
             dist.barrier()
             tg = time.perf_counter()
             for lo in range(0, min(args.steps, ring), CH):
-                dist.gather(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, dst=0, group=data_group)
+                gather_to_rank0(frames_out[lo:lo + CH], gather_bufs[0] if rank == 0 else None, data_group)
             torch.cuda.synchronize()
             dist.barrier()
             gather_ms = 1e3 * (time.perf_counter() - tg)

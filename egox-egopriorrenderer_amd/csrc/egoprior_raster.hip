@@ -1346,21 +1346,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
-        case 5:
-            EP_SWEEP(256, 256, 4);
-            break;
-        case 8:
-            EP_SWEEP(512, 512, 4);
-            break;
-        case 9:
-            EP_SWEEP(256, 256, 3);
-            break;
         case 6:
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, true>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
-                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 7:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 32>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
                       d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 10:

@@ -273,6 +273,56 @@ def test_rasterize_known_answers_and_ties(engine, splat_variant):
     assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+def _ulps(v, n):
+    """float32 v moved by n units in the last place."""
+    v = F32(v)
+    for _ in range(abs(n)):
+        v = np.nextafter(v, F32(np.inf if n > 0 else -np.inf), dtype=F32)
+    return v
+
+
+@pytest.mark.parametrize("size,ps", [((40, 56), 1.0), ((40, 56), 2.5), ((56, 40), 5.0), ((24, 24), 9.0)])
+def test_rasterize_discs_that_touch_pixel_centres_exactly(engine, size, ps, splat_variant, bin_variant):
+    """The binning keeps, per axis, the pixel centres in [c - r, c + r] and drops discs that fall between centres; the
+    splat kernel drops list entries that cannot reach its tile.  Both are conservative by a margin, and this is the case
+    that would show a margin that is too small: discs whose rim lies on a pixel centre, one ulp inside and one ulp
+    outside, on either side of tile borders and of the image border, plus discs centred exactly between pixel centres."""
+    from egoprior import engine as eng
+    He, We = size
+    r = F32(O.radius_ndc(ps, He, We))
+    xf, yf = O.pixel_ndc_centres(He, We)
+    pts = []
+    cols_of_interest = [0, 1, 7, 8, 9, 15, 16, We - 2, We - 1]
+    rows_of_interest = [0, 1, 7, 8, 9, 15, 16, He - 2, He - 1]
+    z = 1.0
+    for xi in cols_of_interest:
+        for yi in rows_of_interest:
+            cx, cy = xf[xi], yf[yi]
+            for sx, sy in ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1)):
+                # a disc whose rim passes through this pixel centre, along an axis or a diagonal
+                k = F32(1.0) if sx == 0 or sy == 0 else F32(np.sqrt(0.5))
+                bx, by = F32(cx + sx * r * k), F32(cy + sy * r * k)
+                for ulps in (0, 1, -1, 4, -4):
+                    px = bx if sx == 0 else _ulps(bx, ulps)
+                    py = by if sy == 0 else _ulps(by, ulps)
+                    z += 0.001
+                    pts.append((px, py, z))
+    # discs centred midway between pixel centres (small radii reach nothing, larger ones reach both neighbours)
+    for xi in (3, 7, 8, We - 2):
+        for yi in (3, 7, 8, He - 2):
+            z += 0.001
+            pts.append((F32((xf[xi] + xf[xi + 1]) / 2), F32((yf[yi] + yf[yi + 1]) / 2), z))
+    ndc = np.array(pts, dtype=F32)
+    rng = np.random.default_rng(7)
+    cols = rng.integers(2, 256, size=(ndc.shape[0], 3), dtype=np.uint8)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, He, We, 20, "scatter")
+    assert (ref_idx >= 0).any()
+    rp = eng.make_raster_params(ps, He, We, K=20, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, He, We, want_fragments=True)
+    assert res["status"].item() == 0
+    _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+
+
 @pytest.mark.parametrize("mode", ["narrow_band", "one_depth_plus_outliers", "few_depths"])
 def test_rasterize_clustered_depths(engine, mode, splat_variant):
     """Depth distributions that defeat equal-width bucketing: a narrow band of depths next to a wide spread, one single

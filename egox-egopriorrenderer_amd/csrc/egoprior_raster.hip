@@ -334,7 +334,7 @@ typedef unsigned long long u64;
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
-__device__ uint32_t g_chunk_stats[8];
+__device__ uint32_t g_chunk_stats[16];
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -998,6 +998,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             // address (a broadcast), subtracted and squared as a float pair, and the hit bit is shifted into the
             // pixel's mask.  Slots past m hold infinite coordinates (written by the sort stage), which never hit.
             uint32_t hm_lo = 0u, hm_hi = 0u;
+#ifdef EP_CHUNK_STATS
+            if (lane == 0) {
+                const bool rm = PIXMAJ && __popcll(act) <= PIXMAJ;
+                atomicAdd(&g_chunk_stats[(rm ? 8 : 6) + (chunk_no > 0 ? 1 : 0)], rm ? (uint32_t)__popcll(act) : 1u);
+                atomicAdd(&g_chunk_stats[10 + (chunk_no > 0 ? 1 : 0)], (uint32_t)__popcll(act));  // open pixels offered
+            }
+#endif
             if (PIXMAJ && __popcll(act) <= PIXMAJ) {
                 // Few pixels are still open: turn the test around.  Every lane holds one record of the block and the
                 // open pixels are visited one by one (their coordinates travel through scalar registers); the
@@ -1235,6 +1242,13 @@ int64_t tiles_per_point_bound(const ep::RasterGeom& g) {
     return bxc * byc;
 }
 
+// list positions are 32-bit: refuse a cloud whose discs could need more entries than that
+int check_list_size(const ep::RasterGeom& g, int64_t n) {
+    if ((uint64_t)n * (uint64_t)tiles_per_point_bound(g) > 0xFFFFFFF0ull)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "too many point-tile pairs for one call (points x tiles per disc > 2^32)");
+    return 0;
+}
+
 struct RasterWs {
     uint32_t* tile_count;   // n_tiles
     uint32_t* tile_start;   // n_tiles + 1
@@ -1270,7 +1284,12 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
 // LDS-aggregated binning needs one 32-bit counter per tile in LDS
 // the counting pass aggregates per workgroup in LDS (two 16-bit counters per word) unless option "bin_lds" is 0
 size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)((n_tiles + 1) >> 1); }
-bool lds_agg_ok(int n_tiles) { return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0; }
+// The LDS histogram has 16-bit counters: it is only used while no workgroup can see 65536 points (the grid stops
+// growing at 4096 workgroups, which then loop over several blocks of EP_BIN_PPB points each).
+bool lds_agg_ok(int n_tiles, int64_t n) {
+    return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0 &&
+           (n + EP_BIN_PPB - 1) / EP_BIN_PPB <= (int64_t)4096 * (65535 / EP_BIN_PPB);
+}
 static_assert(EP_BIN_PPB < 65536, "a workgroup's per-tile count must fit into 16 bits");
 
 int bin_grid(int64_t n) {
@@ -1431,13 +1450,14 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
+    if (int e = check_list_size(g, n)) return e;
     RasterWs w;
     if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, w))
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "raster workspace too small");
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     egoprior_camera cam_unused = {};
-    if (lds_agg_ok(n_tiles))
+    if (lds_agg_ok(n_tiles, n))
         EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256),
                   bin_lds_bytes(n_tiles), s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
                   (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1);
@@ -1469,6 +1489,7 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
     if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
+    if (int e = check_list_size(g, n)) return e;
     const size_t ndc_bytes = align_up((size_t)(n > 0 ? n : 1) * sizeof(egoprior_point), 256);
     if (d_workspace == nullptr || workspace_bytes < ndc_bytes)
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
@@ -1478,7 +1499,7 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
     if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
-    if (lds_agg_ok(n_tiles))
+    if (lds_agg_ok(n_tiles, n))
         EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256),
                   bin_lds_bytes(n_tiles), s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
                   w.total, w.tile_count, 1);
@@ -1491,9 +1512,9 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
 
 #ifdef EP_TILE_TIMES
 extern "C" int egoprior_debug_chunk_stats(uint32_t* host8, int reset) {
-    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_chunk_stats), 8 * sizeof(uint32_t)) != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_chunk_stats), 16 * sizeof(uint32_t)) != hipSuccess) return -3;
     if (reset) {
-        uint32_t z[8] = {0};
+        uint32_t z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_chunk_stats), z, sizeof(z)) != hipSuccess) return -3;
     }
     return 0;

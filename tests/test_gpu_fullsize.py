@@ -128,3 +128,49 @@ def test_two_runs_same_bits(engine, scene):
         b, _ = _render(engine, scene, 5.0, 0)
         for k, v in keep.items():
             assert torch.equal(b[k], v)
+
+
+@pytest.mark.parametrize("bin_lds", [1, 0])
+def test_nine_million_points_against_the_oracle(engine, bin_lds):
+    """More points than the binning grid has blocks for (4096 x 2048): its workgroups loop, and the 16-bit LDS counters
+    of the counting pass take several blocks each.  Most discs miss the small image, so the point-driven oracle stays
+    fast; idx / zbuf / dists must still be bit-exact."""
+    from egoprior import _lib
+    from egoprior import engine as eng
+    rng = np.random.default_rng(3)
+    n, Hs, Ws = 9_000_000, 64, 96
+    ndc = np.empty((n, 3), dtype=np.float32)
+    ndc[:, 0] = rng.uniform(-4, 4, n)
+    ndc[:, 1] = rng.uniform(-3, 3, n)
+    ndc[:, 2] = rng.uniform(0.5, 50, n)
+    ndc[::1000, 2] = -1.0  # behind the camera
+    r = O.radius_ndc(2.0, Hs, Ws)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, Hs, Ws, K, "scatter")
+    rec = torch.zeros((n, 4), dtype=torch.float32, device=engine.device)
+    rec[:, :3] = torch.from_numpy(ndc).to(engine.device)
+    rp = eng.make_raster_params(2.0, Hs, Ws, K=K, colors_gt1=1)
+    _lib.set_option("bin_lds", bin_lds)
+    try:
+        res = engine.rasterize_composite(rec, None, rp, Hs, Ws, want_fragments=True)
+    finally:
+        _lib.set_option("bin_lds", 1)
+    assert res["status"].item() == 0
+    assert np.array_equal(res["idx"].cpu().numpy(), ref_idx)
+    assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z)
+    assert np.array_equal(res["dists"].cpu().numpy(), ref_d)
+
+
+def test_too_many_point_tile_pairs_is_refused(engine):
+    """List positions are 32-bit; a call whose discs could need more entries fails up front instead of overflowing."""
+    import ctypes as C
+    from egoprior import _lib
+    from egoprior import engine as eng
+    rp = eng.make_raster_params(40.0, 64, 64, K=K, colors_gt1=1)  # discs of 40 px: dozens of tiles each
+    dummy = torch.zeros(64, dtype=torch.uint8, device=engine.device)
+    img = torch.zeros((64, 64, 3), dtype=torch.uint8, device=engine.device)
+    n = 0x7FFFFFF0  # nothing is dereferenced: the check comes before any launch
+    rc = engine.L.egoprior_rasterize_composite(C.byref(rp), 64, 64, C.c_void_p(dummy.data_ptr()), n, None, None, None,
+                                               C.c_void_p(img.data_ptr()), None, None, None, None, None,
+                                               C.c_void_p(dummy.data_ptr()), dummy.numel(), None)
+    assert rc == _lib.E_INVALID
+    assert b"point-tile pairs" in engine.L.egoprior_last_error()

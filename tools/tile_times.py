@@ -10,7 +10,8 @@ import numpy as np
 import torch
 from egoprior import _lib
 
-_lib.LIB_PATH = _lib.CSRC / "libegoprior_hip_tiletimes.so"
+_lib.LIB_PATH = _lib.CSRC / ("libegoprior_hip_chunkstats.so" if "--chunks" in sys.argv else "libegoprior_hip_tiletimes.so")
+sys.argv = [a for a in sys.argv if a != "--chunks"]
 from egoprior import engine as eng, synth
 
 ps = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
@@ -31,13 +32,16 @@ rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
 cs = C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_chunk_stats
-cbuf = (C.c_uint32 * 8)()
+cbuf = (C.c_uint32 * 16)()
 cs(cbuf, 1)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
 cs(cbuf, 0)
 c = list(cbuf)
 if c[0]:  # only a build with -DEP_CHUNK_STATS counts these (its atomics distort the wave durations below)
+    print(f"sweep blocks of 64 records, pixel-major: first chunks {c[6]}, later chunks {c[7]}; record-major pixel visits: "
+          f"first {c[8]}, later {c[9]}; open pixels offered per block: first {c[10] / max(c[6] + 1e-9, 1):.1f} "
+          f"(over pixel- and record-major blocks), later total {c[11]}")
     print(f"chunks {c[0]} (records kept {c[3]}); later chunks {c[1]} (kept {c[4]}), of those unfiltered {c[2]} (kept {c[5]})")
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()

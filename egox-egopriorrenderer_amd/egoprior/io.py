@@ -9,8 +9,9 @@ OpenCV:
     float16 or float32, mask/<name>.npy (F,H,W) uint8.  The twin is used when the codec file is absent; synthetic
     sequences are written this way (write_synthetic_artifacts).
   * instance-mask PNGs are decoded by a small pure-Python decoder (8/16-bit greyscale, non-interlaced) when OpenCV is
-    missing; depth EXRs need OpenEXR and RGB mp4s need imageio -- if those are missing and there is no twin, the
-    reader raises with a message that says so.
+    missing, and depth EXRs by a built-in reader of the subset ViPE writes (single-part scan-line file, HALF channel Z,
+    compression none / RLE / ZIPS / ZIP) when OpenEXR is missing; RGB mp4s need imageio -- if it is missing and there is
+    no twin, the reader raises with a message that says so.
 
 Poses are returned as the (F,4,4) matrices stored in the npz (the reference round-trips them through a normalised
 quaternion, vipe/utils/geometry.py:339-344, which changes a valid pose by < 1e-6).
@@ -128,28 +129,28 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
     if zip_file_path.exists():
         try:
             import OpenEXR
-        except ImportError as e:
-            if not _twin(zip_file_path).exists():
-                raise ImportError(f"reading {zip_file_path} needs OpenEXR; no {_twin(zip_file_path).name} twin "
-                                  "found") from e
-        else:
-            vw = vh = 0
-            with zipfile.ZipFile(zip_file_path, "r") as z:
-                for name in sorted(z.namelist()):
-                    idx = int(name.split(".")[0])
-                    with z.open(name) as f:
-                        try:
+        except ImportError:
+            OpenEXR = None  # the built-in reader covers the files ViPE writes (one HALF channel Z, scan lines)
+        vw = vh = 0
+        with zipfile.ZipFile(zip_file_path, "r") as z:
+            for name in sorted(z.namelist()):
+                idx = int(name.split(".")[0])
+                with z.open(name) as f:
+                    try:
+                        if OpenEXR is not None:
                             exr = OpenEXR.InputFile(f)
-                        except OSError:
-                            assert vw > 0 and vh > 0
-                            yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
-                            continue
-                        dw = exr.header()["dataWindow"]
-                        vw, vh = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
-                        buf = exr.channels(["Z"])[0]
-                        half = np.frombuffer(buf, dtype=np.float16).reshape(vh, vw)
-                        yield idx, (half.copy() if keep_half else half.astype(np.float32))
-            return
+                            dw = exr.header()["dataWindow"]
+                            w, h = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
+                            half = np.frombuffer(exr.channels(["Z"])[0], dtype=np.float16).reshape(h, w)
+                        else:
+                            half = decode_exr_half_z(f.read())
+                    except OSError:
+                        assert vw > 0 and vh > 0
+                        yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
+                        continue
+                    vh, vw = half.shape
+                    yield idx, (half.copy() if keep_half else half.astype(np.float32))
+        return
     tw = _twin(zip_file_path)
     if not tw.exists():
         raise FileNotFoundError(str(zip_file_path))
@@ -157,6 +158,154 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
     for i in range(arr.shape[0]):
         a = np.asarray(arr[i])
         yield i, (a.copy() if (keep_half and a.dtype == np.float16) else a.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OpenEXR, the subset ViPE writes: one scan-line part, one HALF channel named Z (vipe/utils/io.py:270-279)
+# ----------------------------------------------------------------------------------------------------------------------
+_EXR_MAGIC = 20000630
+_EXR_NO, _EXR_RLE, _EXR_ZIPS, _EXR_ZIP = 0, 1, 2, 3
+_EXR_LINES = {_EXR_NO: 1, _EXR_RLE: 1, _EXR_ZIPS: 1, _EXR_ZIP: 16}
+
+
+def _exr_unfilter(t: np.ndarray) -> np.ndarray:
+    """Undo the byte predictor and the even / odd byte split OpenEXR applies before deflate (ImfZip: every byte is
+    stored as its difference to the previous one plus 128; the first half of the buffer holds the bytes of even
+    position, the second half those of odd position)."""
+    n = t.size
+    d = np.cumsum(t.astype(np.int64))
+    d[1:] -= 128 * np.arange(1, n, dtype=np.int64)
+    d = (d & 255).astype(np.uint8)
+    out = np.empty(n, dtype=np.uint8)
+    half = (n + 1) // 2
+    out[0::2] = d[:half]
+    out[1::2] = d[half:]
+    return out
+
+
+def _exr_filter(raw: np.ndarray) -> np.ndarray:
+    n = raw.size
+    t = np.concatenate([raw[0::2], raw[1::2]]).astype(np.int64)
+    d = t.copy()
+    d[1:] = t[1:] - t[:-1] + 128
+    return (d & 255).astype(np.uint8)
+
+
+def _exr_unrle(src: bytes, n_out: int) -> np.ndarray:
+    """OpenEXR's run-length code: a count byte c >= 0 repeats the next byte c + 1 times, c < 0 copies -c bytes."""
+    out = bytearray()
+    i = 0
+    while i < len(src) and len(out) < n_out:
+        c = src[i] - 256 if src[i] > 127 else src[i]
+        i += 1
+        if c < 0:
+            out += src[i:i - c]
+            i += -c
+        else:
+            out += bytes([src[i]]) * (c + 1)
+            i += 1
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def decode_exr_half_z(buf: bytes) -> np.ndarray:
+    """(H, W) float16 of channel Z of a single-part scan-line OpenEXR file with compression none, RLE, ZIPS or ZIP.
+    Raises OSError for anything that is not such a file (what OpenEXR.InputFile raises, and what the reference's reader
+    catches to substitute an all-NaN frame, vipe/utils/io.py:293-305)."""
+    try:
+        magic, version = struct.unpack_from("<iI", buf, 0)
+        if magic != _EXR_MAGIC or (version & 0xFF) != 2 or (version & 0x1A00):  # tiled / deep / multi-part bits
+            raise ValueError("not a single-part scan-line OpenEXR file")
+        pos, attrs = 8, {}
+        while buf[pos] != 0:
+            e = buf.index(b"\0", pos)
+            name = buf[pos:e].decode("latin1")
+            e2 = buf.index(b"\0", e + 1)
+            size, = struct.unpack_from("<i", buf, e2 + 1)
+            attrs[name] = buf[e2 + 5:e2 + 5 + size]
+            pos = e2 + 5 + size
+        pos += 1
+        xmin, ymin, xmax, ymax = struct.unpack("<4i", attrs["dataWindow"])
+        W, H = xmax - xmin + 1, ymax - ymin + 1
+        comp = attrs["compression"][0]
+        if comp not in _EXR_LINES:
+            raise ValueError(f"unsupported EXR compression {comp}")
+        channels, c = [], attrs["channels"]
+        q = 0
+        while c[q] != 0:
+            e = c.index(b"\0", q)
+            ptype, _, xs, ys = struct.unpack_from("<iB3xii", c, e + 1)
+            channels.append((c[q:e].decode("latin1"), ptype, xs, ys))
+            q = e + 17
+        if any(xs != 1 or ys != 1 for _, _, xs, ys in channels):
+            raise ValueError("subsampled channels are not supported")
+        names = [n for n, _, _, _ in channels]  # stored in alphabetical order
+        if "Z" not in names or channels[names.index("Z")][1] != 1:
+            raise ValueError("no HALF channel named Z")
+        bpp = [4 if t != 1 else 2 for _, t, _, _ in channels]
+        z_off = sum(bpp[:names.index("Z")]) * W
+        line_bytes = sum(bpp) * W
+        lines = _EXR_LINES[comp]
+        n_chunks = (H + lines - 1) // lines
+        offsets = struct.unpack_from(f"<{n_chunks}Q", buf, pos)
+        out = np.empty((H, W), dtype=np.float16)
+        for off in offsets:
+            y, size = struct.unpack_from("<ii", buf, off)
+            rows = min(lines, ymax - y + 1)
+            raw_size = rows * line_bytes
+            data = buf[off + 8:off + 8 + size]
+            if size > raw_size or len(data) != size:
+                raise ValueError("corrupt chunk")
+            if comp == _EXR_NO or size == raw_size:  # a chunk that does not shrink is stored as it is
+                raw = np.frombuffer(data, dtype=np.uint8)
+            elif comp == _EXR_RLE:
+                raw = _exr_unfilter(_exr_unrle(data, raw_size))
+            else:
+                raw = _exr_unfilter(np.frombuffer(zlib.decompress(data), dtype=np.uint8))
+            if raw.size != raw_size:
+                raise ValueError("chunk has the wrong size")
+            raw = raw.reshape(rows, line_bytes)
+            out[y - ymin:y - ymin + rows] = raw[:, z_off:z_off + 2 * W].copy().view("<f2")
+        return out
+    except (ValueError, KeyError, IndexError, struct.error, zlib.error) as e:
+        raise OSError(f"cannot read EXR data: {e}") from e
+
+
+def encode_exr_half_z(depth: np.ndarray, compression: int = _EXR_ZIP) -> bytes:
+    """The file OpenEXR.OutputFile writes for Header(width, height) with channels {"Z": HALF} (the reference's writer,
+    vipe/utils/io.py:270-279; the library's default compression is ZIP, 16 scan lines per chunk)."""
+    half = np.ascontiguousarray(depth, dtype="<f2")
+    H, W = half.shape
+
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+    box = struct.pack("<4i", 0, 0, W - 1, H - 1)
+    head = struct.pack("<iI", _EXR_MAGIC, 2)
+    head += attr("channels", "chlist", b"Z\0" + struct.pack("<iB3xii", 1, 0, 1, 1) + b"\0")
+    head += attr("compression", "compression", bytes([compression]))
+    head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box)
+    head += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    head += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0))
+    head += attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = _EXR_LINES[compression]
+    chunks = []
+    for y in range(0, H, lines):
+        raw = half[y:y + lines].view(np.uint8).reshape(-1)
+        data = raw.tobytes()
+        if compression in (_EXR_ZIP, _EXR_ZIPS):
+            packed = zlib.compress(_exr_filter(raw).tobytes())
+            if len(packed) < len(data):
+                data = packed
+        elif compression != _EXR_NO:
+            raise ValueError("the writer knows compression none, ZIPS and ZIP")
+        chunks.append(struct.pack("<ii", y, len(data)) + data)
+    table_at = len(head)
+    pos = table_at + 8 * len(chunks)
+    table = b""
+    for ch in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(ch)
+    return head + table + b"".join(chunks)
 
 
 def decode_png_gray(buf: bytes) -> np.ndarray:
@@ -267,7 +416,7 @@ def encode_png_rgb(img: np.ndarray) -> bytes:
 
 
 def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w, mask_as_png_zip: bool = True,
-                              camera_type: str = "PINHOLE"):
+                              camera_type: str = "PINHOLE", depth_as_exr_zip: bool = False):
     """Writes a sequence in the ViPE layout using the array twins for rgb and depth (no codec needed) and, by default,
     the reference's zip-of-PNG container for the instance masks.  depth is stored as float16 like the EXR HALF files."""
     base = Path(base)
@@ -276,7 +425,12 @@ def write_synthetic_artifacts(base: Path, name: str, depth, rgb, mask, intr, c2w
     for sub in ("rgb", "depth", "pose", "intrinsics", "mask"):
         (base / sub).mkdir(parents=True, exist_ok=True)
     np.save(base / "rgb" / f"{name}.npy", rgb.astype(np.uint8))
-    np.save(base / "depth" / f"{name}.npy", depth.astype(np.float16))
+    if depth_as_exr_zip:  # the reference's container: a zip of %05d.exr files, channel Z HALF (vipe/utils/io.py:268-279)
+        with zipfile.ZipFile(base / "depth" / f"{name}.zip", "w", zipfile.ZIP_DEFLATED) as z:
+            for i in range(Fn):
+                z.writestr(f"{i:05d}.exr", encode_exr_half_z(depth[i].astype(np.float16)))
+    else:
+        np.save(base / "depth" / f"{name}.npy", depth.astype(np.float16))
     c2w = np.asarray(c2w, dtype=np.float32)
     if c2w.ndim == 2:
         c2w = np.repeat(c2w[None], Fn, axis=0)

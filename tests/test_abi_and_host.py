@@ -214,3 +214,125 @@ def test_host_ray_tables_follow_the_reference_camera_models():
         ray_table("SIMPLE_DIVISIONAL", [1, 1, 0, 0], H, W, 1)
     with pytest.raises(ValueError):
         ray_table("MEI", [1, 1, 0, 0], H, W, 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# built-in OpenEXR reader (depth artifacts on a machine without the OpenEXR module).  No EXR file ships with the
+# reference and no OpenEXR library exists here, so these files are assembled by hand from the published file layout,
+# independently of the package's own writer: parity with the real library is unpinned.
+# ----------------------------------------------------------------------------------------------------------------------
+def _exr_attr(name, typ, value):
+    import struct
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+
+def _hand_made_exr(planes, compression, lines_per_chunk, data_window=None):
+    """planes: {channel name: (pixel type 1 = HALF / 2 = FLOAT, (H,W) array)}; chunk payloads filtered with plain loops."""
+    import struct
+    import zlib
+    names = sorted(planes)
+    H, W = planes[names[0]][1].shape
+    x0, y0 = data_window or (0, 0)
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", planes[n][0], 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", x0, y0, x0 + W - 1, y0 + H - 1)
+    head = struct.pack("<iI", 20000630, 2)
+    # another attribute order than the package's writer, plus one the reader has never heard of
+    head += _exr_attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    head += _exr_attr("owner", "string", b"hand made")
+    head += _exr_attr("dataWindow", "box2i", box) + _exr_attr("displayWindow", "box2i", box)
+    head += _exr_attr("compression", "compression", bytes([compression]))
+    head += _exr_attr("lineOrder", "lineOrder", b"\0") + _exr_attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    head += _exr_attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + _exr_attr("channels", "chlist", chlist)
+    head += b"\0"
+    chunks = []
+    for y in range(0, H, lines_per_chunk):
+        raw = b""
+        for row in range(y, min(y + lines_per_chunk, H)):
+            for n in names:  # per scan line: the channels one after the other, in alphabetical order
+                t, a = planes[n]
+                raw += a[row].astype("<f2" if t == 1 else "<f4").tobytes()
+        data = raw
+        if compression in (2, 3):
+            t = list(raw[0::2]) + list(raw[1::2])
+            f = [t[0]] + [(t[i] - t[i - 1] + 128) & 255 for i in range(1, len(t))]
+            packed = zlib.compress(bytes(f))
+            data = packed if len(packed) < len(raw) else raw
+        elif compression == 1:
+            t = list(raw[0::2]) + list(raw[1::2])
+            f = bytes([t[0]] + [(t[i] - t[i - 1] + 128) & 255 for i in range(1, len(t))])
+            rle, i = b"", 0
+            while i < len(f):  # runs of 3+ as (count - 1, byte), everything else as literal blocks (-n, bytes)
+                j = i
+                while j + 1 < len(f) and f[j + 1] == f[i] and j - i < 127:
+                    j += 1
+                if j - i >= 2:
+                    rle += bytes([j - i, f[i]])
+                    i = j + 1
+                else:
+                    k = i
+                    while k < len(f) and k - i < 127 and not (k + 2 < len(f) and f[k] == f[k + 1] == f[k + 2]):
+                        k += 1
+                    rle += bytes([256 - (k - i)]) + f[i:k]
+                    i = k
+            data = rle if len(rle) < len(raw) else raw
+        chunks.append(struct.pack("<ii", y0 + y, len(data)) + data)
+    pos = len(head) + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", pos)
+        pos += len(c)
+    return head + table + b"".join(chunks)
+
+
+@pytest.mark.parametrize("compression,lines", [(0, 1), (1, 1), (2, 1), (3, 16)])
+def test_builtin_exr_reader_on_hand_made_files(compression, lines):
+    from egoprior import io as eio
+    rng = np.random.default_rng(compression)
+    H, W = 37, 29
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    z = (2.0 + 0.01 * u + 0.02 * v).astype(np.float16)  # smooth: compresses, so the filtered path is taken
+    z[3, 4], z[5, 6], z[0, 0] = np.nan, np.inf, 0.0
+    z[20:, :5] = rng.random((H - 20, 5)).astype(np.float16)
+    planes = {"Z": (1, z), "A": (1, rng.random((H, W)).astype(np.float16)), "ZZ": (2, rng.random((H, W)).astype(np.float32))}
+    got = eio.decode_exr_half_z(_hand_made_exr(planes, compression, lines, data_window=(3, -2)))
+    assert got.dtype == np.float16 and np.array_equal(got.view(np.uint16), z.view(np.uint16))
+    only_z = eio.decode_exr_half_z(_hand_made_exr({"Z": (1, z)}, compression, lines))
+    assert np.array_equal(only_z.view(np.uint16), z.view(np.uint16))
+    # and the package's own writer produces what the reader (and the hand-made layout) agree on
+    assert np.array_equal(eio.decode_exr_half_z(eio.encode_exr_half_z(z)).view(np.uint16), z.view(np.uint16))
+
+
+def test_builtin_exr_reader_rejects_what_it_cannot_read():
+    from egoprior import io as eio
+    z = np.ones((4, 4), dtype=np.float16)
+    good = _hand_made_exr({"Z": (1, z)}, 3, 16)
+    for bad in (b"", b"not an exr file at all", good[:60], good[:-5],
+                _hand_made_exr({"Y": (1, z)}, 0, 1),               # no channel Z
+                _hand_made_exr({"Z": (2, z)}, 0, 1),               # Z is FLOAT, not HALF
+                _hand_made_exr({"Z": (1, z)}, 4, 32)):             # PIZ
+        with pytest.raises(OSError):
+            eio.decode_exr_half_z(bad)
+
+
+def test_depth_zip_of_exr_files_reads_like_the_reference(tmp_path):
+    """vipe/utils/io.py:282-312: frames in name order, float32 (or float16 kept), an unreadable EXR becomes an all-NaN
+    frame of the last good size."""
+    import zipfile
+    from egoprior import io as eio
+    rng = np.random.default_rng(1)
+    frames = (rng.random((4, 12, 20)) * 8).astype(np.float16)
+    path = tmp_path / "depth" / "clip.zip"
+    path.parent.mkdir()
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as zf:
+        for i in (2, 0, 1, 3):  # stored out of order
+            zf.writestr(f"{i:05d}.exr", b"broken" if i == 2 else eio.encode_exr_half_z(frames[i]))
+    got = list(eio.read_depth_artifacts(path))
+    assert [i for i, _ in got] == [0, 1, 2, 3]
+    for i, d in got:
+        assert d.dtype == np.float32 and d.shape == (12, 20)
+        if i == 2:
+            assert np.isnan(d).all()
+        else:
+            assert np.array_equal(d, frames[i].astype(np.float32))
+    kept = list(eio.read_depth_artifacts(path, keep_half=True))
+    assert kept[0][1].dtype == np.float16 and np.array_equal(kept[3][1], frames[3])

@@ -34,8 +34,10 @@ def test_jobs_over_worker_processes(tmp_path):
             if (take, cam) != ("take_b", "cam04"):  # that one has no ViPE result: its job is skipped, not failed
                 # F - t frames: the renderer insists that the requested range is the clip's range
                 d, rgb, m = [x.numpy() for x in synth.make_frames(H, W, range(t, F), 12)]
+                # take_b stores its depth the way ViPE does, as a zip of EXR files, take_a as the array twin
                 eio.write_synthetic_artifacts(tmp_path / "vipe" / take / sub, "exo", d, rgb, m,
-                                              synth.exo_intrinsics(H, W), np.eye(4, dtype=F32))
+                                              synth.exo_intrinsics(H, W), np.eye(4, dtype=F32),
+                                              depth_as_exr_zip=(take == "take_b"))
             jobs.append(batch.RenderJob(take_name=take, result_subdir=sub, ego_uuid=f"uuid-{take}",
                                         vipe_results_root=str(tmp_path / "vipe"), data_dir=str(tmp_path / "data"),
                                         meta_files_dir=str(tmp_path / "meta"), output_dir=str(tmp_path / "out"),

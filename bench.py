@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="rehearsal of the N > 1 control flow on a box with ONE GPU: every rank uses cuda:0 and the data "
                          "collectives go through gloo (RCCL refuses two ranks on one device); the numbers mean nothing")
+    ap.add_argument("--from-host", action="store_true",
+                    help="the PCIe-inclusive rate: every frame's depth, RGB and mask start in pinned host memory and are "
+                         "copied to the GPU on the frame's own stream inside the timed region (never the headline value)")
     ap.add_argument("--fisheye", action="store_true",
                     help="BASELINE configs[3] instead of configs[1]: fisheye ego camera (the preset Ego-Exo4D radial / "
                          "tangential / thin-prism coefficients), not rotated; combine with --point-size 10 or 20")
@@ -222,12 +225,33 @@ def run(args):
     pipe = eng.FramePipeline(E, bg, rp, He, We, exo_hw=(H, W), subsample=s, slots=args.streams, extra_streams=extra)
     dyn = pipe.dyns[0]
 
-    def step_inputs(i):
+    def step_inputs(i, slot=None):
         f = i % Fl
         return {} if args.no_dynamic else dict(up=up, depth=depth[f], rgb=rgb[f], mask=mask[f])
 
+    if args.from_host:
+        # a window of the clip in pinned host memory and one set of device staging buffers per slot; the copies are
+        # queued on the slot's stream, so they are ordered with that slot's kernels and overlap the other slots' work
+        n_host = min(Fl, 64)
+        h_depth, h_rgb, h_mask = (t[:n_host].cpu().pin_memory() for t in (depth, rgb, mask))
+        stage = [(torch.empty_like(depth[0]), torch.empty_like(rgb[0]), torch.empty_like(mask[0]))
+                 for _ in range(pipe.n_slots)]
+        host_step = [0]
+
+        def step_inputs(i, slot=None):  # noqa: F811  (replaces the resident-clip version above)
+            f = i % n_host
+            k = host_step[0] % pipe.n_slots if slot is None else slot
+            host_step[0] += 1
+            with torch.cuda.stream(pipe.streams[k]):
+                for dst, src in zip(stage[k], (h_depth[f], h_rgb[f], h_mask[f])):
+                    dst.copy_(src, non_blocking=True)
+            return dict(up=up, depth=stage[k][0], rgb=stage[k][1], mask=stage[k][2], slot=k)
+
     def step(i, slot=None):
-        pipe.submit(cams[i % Fl], frames_out[i % ring], slot=slot, **step_inputs(i))
+        kw = step_inputs(i, slot)
+        if slot is not None:
+            kw["slot"] = slot
+        pipe.submit(cams[i % Fl], frames_out[i % ring], **kw)
 
     # N > 1: every finished block of CH frames is gathered on rank 0 while the next block renders (the collective runs
     # on RCCL's own stream, ordered after the block by pipe.join()); all K frames of every rank arrive within the timed
@@ -408,6 +432,7 @@ def run(args):
                                f"{args.point_size}, K=20, {Fl} exo frames/rank resident in HBM",
                    "exo": [H, W], "ego": [He, We], "point_size": args.point_size, "subsample": s, "depth_dtype": "f16" if args.depth_f16 else "f32",
                    "frames_per_rank": Fl, "static_points": n_bg, "frames_in_flight": pipe.n_slots,
+                   "inputs": "pinned host memory, copied per frame inside the timed region" if args.from_host else "resident in HBM",
                    "parallelism": f"frames sharded x{world}"},
         "gpoints_per_s": round(pts_entering / elapsed / 1e9, 4),
         "points_entering_raster_per_frame": round(n_avg, 1),

@@ -78,6 +78,35 @@ def _twin(path: Path) -> Path:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def _decode_ahead(z: zipfile.ZipFile, names, decode, workers: Optional[int] = None):
+    """Yields (name, decode(bytes of the member)) in the order of `names`.  The members are read from the archive one
+    after the other (the archive object is not thread-safe) and decoded by a few worker threads, a bounded number of
+    frames ahead of the consumer: inflate and the large numpy operations of the built-in decoders release the GIL, so
+    a 1080p clip decodes several times faster than frame by frame.  An exception raised by `decode` is delivered in
+    place of the result, so that the caller can treat that frame the way the reference does."""
+    import os
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    def guarded(data):
+        try:
+            return decode(data)
+        except Exception as e:  # handed to the consumer, in order
+            return e
+
+    workers = workers or max(1, min(8, (os.cpu_count() or 2) - 1))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        ahead = deque()
+        for name in names:
+            ahead.append((name, pool.submit(guarded, z.read(name))))
+            if len(ahead) > 2 * workers:
+                n, fut = ahead.popleft()
+                yield n, fut.result()
+        while ahead:
+            n, fut = ahead.popleft()
+            yield n, fut.result()
+
+
 def read_pose_artifacts(npz_file_path: Path):
     """(inds (F,), c2w (F,4,4) float32) -- OpenCV camera-to-world matrices."""
     data = np.load(npz_file_path)
@@ -133,22 +162,31 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
             OpenEXR = None  # the built-in reader covers the files ViPE writes (one HALF channel Z, scan lines)
         vw = vh = 0
         with zipfile.ZipFile(zip_file_path, "r") as z:
-            for name in sorted(z.namelist()):
+            names = sorted(z.namelist())
+            if OpenEXR is None:
+                for name, half in _decode_ahead(z, names, decode_exr_half_z):
+                    idx = int(name.split(".")[0])
+                    if isinstance(half, OSError):
+                        assert vw > 0 and vh > 0
+                        yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
+                        continue
+                    if isinstance(half, Exception):
+                        raise half
+                    vh, vw = half.shape
+                    yield idx, (half if keep_half else half.astype(np.float32))
+                return
+            for name in names:
                 idx = int(name.split(".")[0])
                 with z.open(name) as f:
                     try:
-                        if OpenEXR is not None:
-                            exr = OpenEXR.InputFile(f)
-                            dw = exr.header()["dataWindow"]
-                            w, h = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
-                            half = np.frombuffer(exr.channels(["Z"])[0], dtype=np.float16).reshape(h, w)
-                        else:
-                            half = decode_exr_half_z(f.read())
+                        exr = OpenEXR.InputFile(f)
                     except OSError:
                         assert vw > 0 and vh > 0
                         yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
                         continue
-                    vh, vw = half.shape
+                    dw = exr.header()["dataWindow"]
+                    vw, vh = dw.max.x - dw.min.x + 1, dw.max.y - dw.min.y + 1
+                    half = np.frombuffer(exr.channels(["Z"])[0], dtype=np.float16).reshape(vh, vw)
                     yield idx, (half.copy() if keep_half else half.astype(np.float32))
         return
     tw = _twin(zip_file_path)
@@ -173,9 +211,8 @@ def _exr_unfilter(t: np.ndarray) -> np.ndarray:
     stored as its difference to the previous one plus 128; the first half of the buffer holds the bytes of even
     position, the second half those of odd position)."""
     n = t.size
-    d = np.cumsum(t.astype(np.int64))
-    d[1:] -= 128 * np.arange(1, n, dtype=np.int64)
-    d = (d & 255).astype(np.uint8)
+    d = np.cumsum(t, dtype=np.uint8)  # wraps modulo 256, which is the arithmetic of the format
+    d[1::2] ^= 0x80                   # minus 128 * position: 128 at odd positions, 0 at even ones (mod 256)
     out = np.empty(n, dtype=np.uint8)
     half = (n + 1) // 2
     out[0::2] = d[:half]
@@ -370,15 +407,16 @@ def read_instance_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarr
             import cv2
         except ImportError:
             cv2 = None
+        def decode(data):
+            if cv2 is not None:
+                return np.asarray(cv2.imdecode(np.frombuffer(data, dtype=np.uint8), cv2.IMREAD_UNCHANGED)).astype(np.uint8)
+            return decode_png_gray(data).astype(np.uint8)
+
         with zipfile.ZipFile(zip_file_path, "r") as z:
-            for name in sorted(z.namelist()):
-                idx = int(name.split(".")[0])
-                data = z.read(name)
-                if cv2 is not None:
-                    m = cv2.imdecode(np.frombuffer(data, dtype=np.uint8), cv2.IMREAD_UNCHANGED)
-                else:
-                    m = decode_png_gray(data)
-                yield idx, np.asarray(m).astype(np.uint8)
+            for name, m in _decode_ahead(z, sorted(z.namelist()), decode):
+                if isinstance(m, Exception):
+                    raise m
+                yield int(name.split(".")[0]), m
         return
     tw = _twin(zip_file_path)
     if not tw.exists():

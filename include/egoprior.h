@@ -170,7 +170,8 @@ int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_
  *   d_idx, d_zbuf, d_dists (H,W,K) int32 / f32 / f32, -1 pad  -- rasterize_points' three outputs
  * Workspace: egoprior_raster_workspace_bytes(H, W, n, radius); a frame whose tile lists outgrow it sets the int32 at
  * d_status to 1 (else 0) and drops the entries that do not fit.  The size the query returns reserves, for every point,
- * the largest number of tiles a disc of that radius can overlap, so it cannot overflow for that n.
+ * the largest number of tiles a disc of that radius can overlap, so it cannot overflow for that n.  List positions are
+ * 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused with EGOPRIOR_E_INVALID (split the cloud).
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
 int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, int32_t W, const egoprior_point* d_ndc,

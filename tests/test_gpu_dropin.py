@@ -202,3 +202,42 @@ def test_non_pinhole_exo_cameras(engine, tmp_path, camera_type):
         qp, qc = O.unproject_frame(d[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "dynamic", rays=rays)
         img = O.render_points_pinhole(np.vstack([ref_p, qp]), np.vstack([ref_c, qc]), K_ego, egos[f], 96, 80, 3.0)
         assert np.array_equal(frames[f], img), f"frame {f}"
+
+
+def test_config_a_49_frames_through_the_cli(tmp_path):
+    """BASELINE configs[0]: a 49-frame 480x832 clip with a fixed exo pose, the reference's defaults (spatial_subsample 2,
+    accumulated static cloud of all frames -- 4.6 M points -- plus each frame's dynamic points, pinhole ego camera,
+    448x448 output rotated 90 degrees), run through main() like scripts/render_vipe.sh does.  Three of the 49 frames are
+    rebuilt with the CPU oracle and must match bit for bit; every frame must contain something."""
+    from egoprior import io as eio, render_vipe_pointcloud as rv, synth
+    F, H, W = 49, 480, 832
+    d, rgb, m = [t.numpy() for t in synth.make_frames(H, W, range(F), F)]
+    intr = synth.exo_intrinsics(H, W)
+    base = tmp_path / "vipe_results" / "clip_a"
+    eio.write_synthetic_artifacts(base, "exo", d, rgb, m, intr, np.eye(4, dtype=F32), depth_as_exr_zip=True)
+    fx = synth.load_camera_fixture()
+    exo = synth.exo_w2c(fx)
+    egos = [np.asarray(e, dtype=F32) for e in synth.ego_orbit_w2c(F, exo)]
+    K_ego = np.array([[150.0, 0, 224.0], [0, 150.0, 224.0], [0, 0, 1]], dtype=F32)
+    meta = {"test_datasets": [{"exo_path": "./videos/clip_a/exo.mp4",
+                               "camera_intrinsics": fx["cam01"]["camera_intrinsics"],
+                               "camera_extrinsics": exo[:3].tolist(), "ego_intrinsics": K_ego.tolist(),
+                               "ego_extrinsics": [e[:3].tolist() for e in egos]}]}
+    (tmp_path / "meta.json").write_text(json.dumps(meta))
+    rv.main(["--input_dir", str(base), "--out_dir", str(tmp_path / "out"), "--meta_json_path", str(tmp_path / "meta.json"),
+             "--point_size", "3.0", "--start_frame", "0", "--end_frame", str(F - 1)])
+    out = tmp_path / "out" / "clip_a"
+    if (out / "ego_Prior.mp4").exists():
+        pytest.skip("mp4 written (imageio present); pixel comparison needs the lossless twin")
+    frames = np.load(out / "ego_Prior.npy")
+    assert frames.shape == (F, 448, 448, 3) and all(frames[f].any() for f in range(F))
+    T = np.linalg.inv(exo)
+    d16 = d.astype(np.float16).astype(F32)  # what the EXR files hold
+    parts = [O.unproject_frame(d16[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "static") for f in range(F)]
+    bp, bc = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    assert bp.shape[0] > 4_000_000
+    for f in (0, 24, 48):
+        dp, dc = O.unproject_frame(d16[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "dynamic")
+        pts, cols = (np.vstack([bp, dp]), np.vstack([bc, dc])) if dp.size else (bp, bc)
+        ref = O.render_points_pinhole(pts, cols, K_ego, egos[f], 448, 448, 3.0)
+        assert np.array_equal(frames[f], ref), f"frame {f}"

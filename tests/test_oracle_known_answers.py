@@ -168,3 +168,34 @@ def test_white_pixel_mask_known_answers():
     logical, vis = O.white_pixel_mask(f, 30.0)
     assert logical.tolist() == [[1, 0, 1], [0, 1, 0]]
     assert vis.max() == 255 and vis.dtype == np.uint8
+
+
+def test_config_a_plumbing_on_the_cpu():
+    """BASELINE configs[0] is the reference's own CPU-runnable case (480x832 exo, subsample 2, pinhole ego 448x448):
+    the oracle runs it end to end -- unprojection of two frames, filters, projection, the naive per-pixel rasterizer on a
+    band of rows against the point-driven one, compositor, post-processing."""
+    from egoprior import synth
+    F32 = np.float32
+    H, W = 480, 832
+    d, rgb, m = [t.numpy() for t in synth.make_frames(H, W, [0, 24], 49)]
+    intr = synth.exo_intrinsics(H, W)
+    exo = synth.exo_w2c()
+    T = np.linalg.inv(exo)
+    parts = [O.unproject_frame(d[f], rgb[f], m[f], intr, np.eye(4, dtype=F32), T, 2, "static") for f in range(2)]
+    dp, dc = O.unproject_frame(d[1], rgb[1], m[1], intr, np.eye(4, dtype=F32), T, 2, "dynamic")
+    pts = np.concatenate([p[0] for p in parts] + [dp])
+    cols = np.concatenate([p[1] for p in parts] + [dc])
+    assert 150_000 < pts.shape[0] <= 2 * 240 * 416 and dp.shape[0] > 0
+    K_ego = np.array([[150.0, 0, 224.0], [0, 150.0, 224.0], [0, 0, 1]], dtype=F32)
+    R, t = np.asarray(synth.ego_orbit_w2c(49, exo)[24], dtype=F32)[:3, :3], np.asarray(synth.ego_orbit_w2c(49, exo)[24], dtype=F32)[:3, 3]
+    p32, c01 = O.filter_points(pts, cols)
+    ndc = O.project_pinhole(p32, R, t, K_ego, 448, 448)
+    r = O.radius_ndc(1.0, 448, 448)
+    idx_s, z_s, d_s = O.rasterize(ndc, r, 448, 448, 20, "scatter")
+    idx_n, z_n, d_n = O.rasterize(ndc, r, 448, 448, 20, "naive", rows=(220, 228))
+    assert np.array_equal(idx_n[220:228], idx_s[220:228]) and np.array_equal(z_n[220:228], z_s[220:228])
+    assert np.array_equal(d_n[220:228], d_s[220:228])
+    img = O.postprocess(O.composite(idx_s, d_s, c01, r), rotate_cw=True)
+    assert img.shape == (448, 448, 3) and img.dtype == np.uint8 and img.any()
+    whole = O.render_points_pinhole(pts, cols, K_ego, np.asarray(synth.ego_orbit_w2c(49, exo)[24], dtype=F32), 448, 448, 1.0)
+    assert np.array_equal(whole, img)

@@ -368,12 +368,13 @@ def test_rasterize_empty_and_all_behind(engine):
     assert (res["image"].cpu().numpy() == 0).all()
 
 
+@pytest.mark.parametrize("ps", [3.0, 20.0])
 @pytest.mark.parametrize("fisheye", [False, True])
-def test_render_frame_end_to_end(engine, fisheye, splat_variant):
-    """static + dynamic clouds built on the GPU from a synthetic frame, rendered from an ego pose."""
+def test_render_frame_end_to_end(engine, fisheye, ps, splat_variant):
+    """static + dynamic clouds built on the GPU from a synthetic frame, rendered from an ego pose; point_size 20 is the
+    many-pixels-per-point case (BASELINE configs[3]: discs of 28 pixels across, every tile list several chunks long)."""
     from egoprior import _lib, engine as eng
     He, We = (112, 112) if fisheye else (96, 160)
-    ps = 3.0
     clip = synthetic_clip(120, 208, 2)
     K, R, t, fe, _ = _cams(clip, He, We)
     args = (clip["depth"][1], clip["rgb"][1], clip["mask"][1], clip["intr"], clip["c2w"], clip["T"])

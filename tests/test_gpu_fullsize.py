@@ -174,3 +174,26 @@ def test_too_many_point_tile_pairs_is_refused(engine):
                                                C.c_void_p(dummy.data_ptr()), dummy.numel(), None)
     assert rc == _lib.E_INVALID
     assert b"point-tile pairs" in engine.L.egoprior_last_error()
+
+
+def test_twenty_million_points_on_a_1024_square_image(engine):
+    """The scale of BASELINE configs[4] (tens of millions of accumulated points, 1024 x 1024 ego): about 1 900 points
+    cover every pixel and every tile list is some twenty chunks long, so almost all of the work is in the later-chunk
+    path (threshold filter, per-pixel prefix, merge network).  The point-driven oracle still finishes in seconds."""
+    from egoprior import engine as eng
+    rng = np.random.default_rng(5)
+    n, S = 20_000_000, 1024
+    ndc = np.empty((n, 3), dtype=np.float32)
+    ndc[:, 0] = rng.uniform(-1.1, 1.1, n)
+    ndc[:, 1] = rng.uniform(-1.1, 1.1, n)
+    ndc[:, 2] = rng.uniform(0.5, 50, n)
+    r = O.radius_ndc(3.0, S, S)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, S, S, K, "scatter")
+    rec = torch.zeros((n, 4), dtype=torch.float32, device=engine.device)
+    rec[:, :3] = torch.from_numpy(ndc).to(engine.device)
+    rp = eng.make_raster_params(3.0, S, S, K=K, colors_gt1=1)
+    res = engine.rasterize_composite(rec, None, rp, S, S, want_fragments=True)
+    assert res["status"].item() == 0
+    assert np.array_equal(res["idx"].cpu().numpy(), ref_idx)
+    assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z)
+    assert np.array_equal(res["dists"].cpu().numpy(), ref_d)

@@ -366,33 +366,42 @@ def decode_png_gray(buf: bytes) -> np.ndarray:
     bpp = depth // 8
     stride = w * bpp
     raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, stride + 1)
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        ft = int(raw[y, 0])
-        line = raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        else:
-            cur = np.zeros(stride, dtype=np.int32)
-            for x in range(stride):
-                a = cur[x - bpp] if x >= bpp else 0
-                b = prev[x]
-                c = prev[x - bpp] if x >= bpp else 0
-                if ft == 1:
-                    p = a
-                elif ft == 3:
-                    p = (a + b) >> 1
-                elif ft == 4:
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                else:
-                    raise ValueError("bad PNG filter")
-                cur[x] = (line[x] + p) & 255
-        out[y] = cur
-        prev = cur
+    ftypes = raw[:, 0]
+    if not ftypes.any():  # every row stored as it is: nothing to undo
+        out = np.ascontiguousarray(raw[:, 1:])
+    else:
+        out = np.zeros((h, stride), dtype=np.uint8)
+        prev = np.zeros(stride, dtype=np.uint8)
+        for y in range(h):
+            ft = int(ftypes[y])
+            line = raw[y, 1:]
+            if ft == 0:
+                cur = line
+            elif ft == 2:  # Up: uint8 arithmetic wraps modulo 256, which is the arithmetic of the format
+                cur = line + prev
+            elif ft == 1:  # Sub: a running sum along the row, one per byte lane of a pixel
+                cur = np.empty(stride, dtype=np.uint8)
+                for c in range(bpp):
+                    cur[c::bpp] = np.cumsum(line[c::bpp], dtype=np.uint8)
+            elif ft in (3, 4):  # Average / Paeth depend on the pixel just decoded: one step per byte
+                cur = np.zeros(stride, dtype=np.uint8)
+                ln, pv = line.tolist(), prev.tolist()
+                res = [0] * stride
+                for x in range(stride):
+                    left = res[x - bpp] if x >= bpp else 0
+                    up = pv[x]
+                    if ft == 3:
+                        pred = (left + up) >> 1
+                    else:
+                        ul = pv[x - bpp] if x >= bpp else 0
+                        pa, pb, pc = abs(up - ul), abs(left - ul), abs(left + up - 2 * ul)
+                        pred = left if (pa <= pb and pa <= pc) else (up if pb <= pc else ul)
+                    res[x] = (ln[x] + pred) & 255
+                cur[:] = res
+            else:
+                raise ValueError("bad PNG filter")
+            out[y] = cur
+            prev = out[y]
     if depth == 16:
         o = out.reshape(h, w, 2).astype(np.uint16)
         return o[..., 0] * 256 + o[..., 1]

@@ -336,3 +336,46 @@ def test_depth_zip_of_exr_files_reads_like_the_reference(tmp_path):
             assert np.array_equal(d, frames[i].astype(np.float32))
     kept = list(eio.read_depth_artifacts(path, keep_half=True))
     assert kept[0][1].dtype == np.float16 and np.array_equal(kept[3][1], frames[3])
+
+
+def _png_with_filters(img, filters):
+    """A greyscale PNG whose rows use the given filter types in turn (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth), written
+    from the PNG specification with plain integer arithmetic."""
+    import struct
+    import zlib
+    h, w = img.shape
+    bpp = 1 if img.dtype == np.uint8 else 2
+    by = img.astype(">u2").view(np.uint8).reshape(h, w * 2) if bpp == 2 else img
+    rows, prev = [], np.zeros(by.shape[1], np.int32)
+    for y in range(h):
+        cur, ft = by[y].astype(np.int32), filters[y % len(filters)]
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if ft == 0:
+            f = cur
+        elif ft == 1:
+            f = cur - left
+        elif ft == 2:
+            f = cur - prev
+        elif ft == 3:
+            f = cur - ((left + prev) >> 1)
+        else:
+            pa, pb, pc = abs(prev - ul), abs(left - ul), abs(left + prev - 2 * ul)
+            f = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        rows.append(bytes([ft]) + (f & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8 * bpp, 0, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("filters", [[0], [1], [2], [3], [4], [0, 1, 2, 3, 4], [4, 2, 1]])
+def test_builtin_png_decoder_undoes_every_filter_type(dtype, filters):
+    """OpenCV picks a filter per row when it writes the instance masks; the built-in decoder has to undo all five."""
+    from egoprior import io as eio
+    img = np.random.default_rng(len(filters)).integers(0, np.iinfo(dtype).max, size=(23, 31)).astype(dtype)
+    assert np.array_equal(eio.decode_png_gray(_png_with_filters(img, filters)), img)

@@ -1,0 +1,50 @@
+"""End-to-end timing of the drop-in CLI on a synthetic 1080p clip written in the reference's containers (depth: zip of EXR
+files, masks: zip of PNG files; RGB as the array twin, since an mp4 needs imageio): where the wall time of
+render_vipe_pointcloud.main goes once rendering itself takes a fraction of a millisecond per frame.
+usage: python tools/cli_timing.py [frames] [--fisheye]"""
+import cProfile
+import json
+import pstats
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "egox-egopriorrenderer_amd")]
+import numpy as np
+
+from egoprior import io as eio, render_vipe_pointcloud as rv, synth
+
+F = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
+H, W = 1080, 1920
+with tempfile.TemporaryDirectory() as tmp:
+    tmp = Path(tmp)
+    t0 = time.time()
+    d, rgb, m = [t.numpy() for t in synth.make_frames(H, W, range(F), F)]
+    base = tmp / "vipe" / "clip"
+    eio.write_synthetic_artifacts(base, "exo", d, rgb, m, synth.exo_intrinsics(H, W), np.eye(4, dtype=np.float32),
+                                  depth_as_exr_zip=True)
+    fx = synth.load_camera_fixture()
+    exo = synth.exo_w2c(fx)
+    egos = synth.ego_orbit_w2c(F, exo)
+    K_ego = [[150.0, 0, 224.0], [0, 150.0, 224.0], [0, 0, 1]]
+    (tmp / "meta.json").write_text(json.dumps({"test_datasets": [{
+        "exo_path": "./videos/clip/exo.mp4", "camera_intrinsics": fx["cam01"]["camera_intrinsics"],
+        "camera_extrinsics": exo[:3].tolist(), "ego_intrinsics": K_ego,
+        "ego_extrinsics": [np.asarray(e)[:3].tolist() for e in egos]}]}))
+    (tmp / "calib.jsonl").write_text(json.dumps(fx["online_calibration_line0"]) + "\n")
+    print(f"clip of {F} frames written in {time.time() - t0:.1f} s", flush=True)
+    argv = ["--input_dir", str(base), "--out_dir", str(tmp / "out"), "--meta_json_path", str(tmp / "meta.json"),
+            "--point_size", "5.0", "--start_frame", "0", "--end_frame", str(F - 1)]
+    if "--fisheye" in sys.argv:
+        argv += ["--fish_eye_rendering", "--use_mean_bg", "--online_calibration_path", str(tmp / "calib.jsonl")]
+    rv.main(argv[:-2] + ["--end_frame", str(F - 1)])  # warm-up: library load, first-touch allocations
+    t0 = time.time()
+    pr = cProfile.Profile()
+    pr.enable()
+    rv.main(argv)
+    pr.disable()
+    dt = time.time() - t0
+    print(f"main(): {dt:.2f} s for {F} frames = {F / dt:.1f} frames/s end to end", flush=True)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)

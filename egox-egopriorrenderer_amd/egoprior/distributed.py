@@ -45,25 +45,30 @@ def gather_frames(dist, local_frames, n_total: int, rank: int, world: int, devic
     shape = tuple(local_frames.shape[1:])
     pad = torch.zeros((n_max,) + shape, dtype=torch.uint8, device=device)
     pad[:local_frames.shape[0]] = local_frames
+    if dist.get_backend() == "gloo":  # gloo gathers host tensors only
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, bufs, dst=0)
     if rank != 0:
         return None
-    return torch.cat([bufs[r][:len(shard_range(n_total, r, world))] for r in range(world)], dim=0)
+    return torch.cat([bufs[r][:len(shard_range(n_total, r, world))] for r in range(world)], dim=0).to(device)
 
 
 def allgather_clouds(dist, points, count: int, world: int, device):
     """All ranks receive the concatenation, in rank order, of every rank's first `count` rows of `points` (n,4)."""
     import torch
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([count], dtype=torch.int64, device=device))
+    cdev = "cpu" if dist.get_backend() == "gloo" else device
+    counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([count], dtype=torch.int64, device=cdev))
     counts = [int(c.item()) for c in counts]
     n_max = max(max(counts), 1)
     pad = torch.zeros((n_max, points.shape[1]), dtype=points.dtype, device=device)
     pad[:count] = points[:count]
+    if dist.get_backend() == "gloo":  # all_gather of device tensors is an RCCL matter; gloo takes the host path
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0), counts
+    return torch.cat([bufs[r][:counts[r]] for r in range(world)], dim=0).to(device), counts
 
 
 def main_distributed(argv=None):
@@ -79,10 +84,16 @@ def main_distributed(argv=None):
     logging.basicConfig(level=logging.INFO)
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args = rv.get_parser().parse_args(argv)
+    if args.dist_backend == "gloo":  # ranks may share GPUs
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist.init_process_group(backend="nccl", device_id=device)
-    args = rv.get_parser().parse_args(argv)
+    if args.dist_backend == "gloo":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=device)
     args.out_dir = rv.configure_output_directory(args)
     if rank == 0:
         os.makedirs(args.out_dir, exist_ok=True)

@@ -504,6 +504,9 @@ def get_parser():
                    help="also write frame_%%06d.png next to the video and print the white-pixel metrics the batch "
                         "scripts derive from such a dump (data_preprocess/scripts/postprocess_render_dir.py)")
     p.add_argument("--white_threshold", type=float, default=30.0, help="grey threshold of the white-pixel metrics")
+    p.add_argument("--dist_backend", choices=["nccl", "gloo"], default="nccl",
+                   help="under torchrun only: nccl (RCCL over xGMI, one rank per GPU) or gloo, with which several ranks "
+                        "may share a GPU (a rehearsal of the multi-GPU path on a one-GPU machine)")
     return p
 
 

@@ -241,3 +241,38 @@ def test_config_a_49_frames_through_the_cli(tmp_path):
         pts, cols = (np.vstack([bp, dp]), np.vstack([bc, dc])) if dp.size else (bp, bc)
         ref = O.render_points_pinhole(pts, cols, K_ego, egos[f], 448, 448, 3.0)
         assert np.array_equal(frames[f], ref), f"frame {f}"
+
+
+@pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_onlybg"])
+def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode):
+    """The multi-GPU path of the CLI (frames sharded over ranks, static cloud all-gathered or mean background
+    all-reduced, frames gathered on rank 0) with two ranks.  This box has one GPU, so both ranks use it and the
+    collectives go through gloo (--dist_backend gloo); everything else is the code an 8-GPU node runs.  The accumulated
+    cloud is the same points in the same order, so those frames are the single-process bits; per-rank partial sums of
+    the mean background may move a mean by one unit in the last place."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from egoprior import render_vipe_pointcloud as rv
+    c = clip_dir
+    argv = ["--input_dir", str(c["base"]), "--meta_json_path", str(c["meta"]), "--point_size", "4.0",
+            "--start_frame", "0", "--end_frame", str(c["F"] - 1)]
+    if mode == "meanbg_fisheye_onlybg":
+        argv += ["--fish_eye_rendering", "--use_mean_bg", "--only_bg", "--online_calibration_path", str(c["calib"])]
+    rv.main(argv + ["--out_dir", str(tmp_path / "one")])
+    script = Path(rv.__file__).resolve().parents[1] / "scripts" / "render_vipe_pointcloud.py"
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), *argv,
+                          "--out_dir", str(tmp_path / "two"), "--dist_backend", "gloo"],
+                         capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, run.stderr[-3000:]
+    one, two = tmp_path / "one" / "take01", tmp_path / "two" / "take01"
+    if (one / "ego_Prior.mp4").exists():
+        pytest.skip("mp4 written (imageio present); pixel comparison needs the lossless twin")
+    a, b = np.load(one / "ego_Prior.npy"), np.load(two / "ego_Prior.npy")
+    assert a.shape == b.shape == (c["F"], 448, 448, 3) and a.any()
+    if mode == "accumulated_pinhole_dyn":
+        assert np.array_equal(a, b)
+    else:
+        diff = np.abs(a.astype(int) - b.astype(int))
+        assert diff.max() <= 2 and (diff > 0).mean() < 1e-3

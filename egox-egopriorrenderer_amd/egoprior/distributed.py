@@ -145,23 +145,13 @@ def main_distributed(argv=None):
     rad = tan = thin = foc = pp = None
     if args.fish_eye_rendering:
         rad, tan, thin, foc, pp = rv.load_aria_distortion_coeffs(args.online_calibration_path, frame_idx=0)
-    out = []
-    for slot in my_slots:
-        dyn = None
-        if not args.only_bg and slot < n_frames:
-            c2w, rgb, intr, ct, depth, mask = frames[slot]
-            if depth is not None and mask is not None:
-                dyn = E.unproject_frame(depth, rgb, mask, intr, c2w, T, subsample=s, select=_lib.SELECT_DYNAMIC)
-        Tw = ego_list[to_render[slot]]
-        if args.fish_eye_rendering:
-            img = rv.render_points_fisheye(None, None, Tw, ego_K, W=size[1], H=size[0], point_size=args.point_size,
-                                           radial_distortion_coeffs=rad, tangential_distortion_coeffs=tan,
-                                           thinPrism_distortion_coeffs=thin, focal_length=foc, principal_point=pp,
-                                           original_image_size=(2880, 2880), _cloud=bg, _dyn=dyn)
-        else:
-            img = rv.render_points_pytorch3d(None, None, K=ego_K, T_w2c=Tw, W=size[1], H=size[0],
-                                             point_size=args.point_size, _cloud=bg, _dyn=dyn)
-        out.append(torch.from_numpy(img).to(device))
+    # this rank's block of frames goes through the same pipelined frame loop as the single-GPU CLI
+    items = None
+    if not args.only_bg:
+        items = iter([frames[slot] if slot < n_frames else None for slot in my_slots])
+    imgs = rv._render_sequence(bg, items, [ego_list[to_render[slot]] for slot in my_slots], ego_K, size,
+                               args.point_size, args.fish_eye_rendering, (rad, tan, thin, foc, pp), (2880, 2880), T)
+    out = [torch.from_numpy(np.ascontiguousarray(img)).to(device) for img in imgs]
     local = torch.stack(out) if out else torch.zeros((0, size[0], size[1], 3), dtype=torch.uint8, device=device)
     allf = gather_frames(dist, local, len(to_render), rank, world, device)
     if rank == 0:

@@ -402,10 +402,22 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
         rad, tan, thin, foc, pp = load_aria_distortion_coeffs(online_calibration_path, frame_idx=0)
         if rad is None or tan is None or thin is None:
             raise ValueError("Failed to load distortion coefficients.")
-    E = _engine()
     bg = _upload(bg_points_3d, bg_colors)  # uploaded and filtered once; the filters are per point
     want_dyn = (not only_bg) and artifact_path is not None and T_cam_to_world is not None
     frames = _frames(artifact_path, tolerant=False) if want_dyn else None
+    return _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size, point_size, use_fisheye,
+                            (rad, tan, thin, foc, pp), aria_size, T_cam_to_world)
+
+
+def _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size, point_size, use_fisheye, coeffs,
+                     aria_size, T_cam_to_world) -> List[np.ndarray]:
+    """The frame loop proper on a static cloud that is already in HBM.  `frames`: None (static cloud only) or an iterator
+    of (c2w, rgb, intr, camera type, depth, mask), one item per ego pose, whose dynamic points join the static cloud."""
+    height, width = image_size
+    num_frames = len(ego_extrinsics_list)
+    rad, tan, thin, foc, pp = coeffs
+    E = _engine()
+    want_dyn = frames is not None
     tables = _RayTables()
 
     def camera(T_w2c):

@@ -108,8 +108,10 @@ def main_distributed(argv=None):
     mine = shard_range(n_frames, rank, world)
     s = 2
     # ---- static cloud ---------------------------------------------------------------------------------------------
-    first = frames[0]
+    first = next((f for f in frames if f[4] is not None), frames[0])  # first usable frame: its intrinsics and camera
+    # type serve every frame of the accumulated cloud, as in the single-GPU builder (the reference builds its rays once)
     H, W = first[1].shape[:2]
+    tables = rv._RayTables()  # device ray tables of non-pinhole exo cameras (None for PINHOLE)
     if args.use_mean_bg:
         state = E.meanbg_new_state(H, W)
         k = 0
@@ -123,14 +125,16 @@ def main_distributed(argv=None):
         allreduce_mean_state(dist, sums, cnt)
         E.meanbg_import(state, sums, cnt)
         md, mc = E.meanbg_finalize(state)
-        bg = E.unproject_frame(md, mc, None, first[2], first[0], T, subsample=s, select=_lib.SELECT_ALL)
+        bg = E.unproject_frame(md, mc, None, first[2], first[0], T, subsample=s, select=_lib.SELECT_ALL,
+                               rays=tables.get(first[3], first[2], H, W, s))
     else:
         parts = []
         for f in mine:
             c2w, rgb, intr, ct, depth, mask = frames[f]
             if depth is None:
                 continue
-            c = E.unproject_frame(depth, rgb, mask, intr, c2w, T, subsample=s, select=_lib.SELECT_STATIC)
+            c = E.unproject_frame(depth, rgb, mask, first[2], c2w, T, subsample=s, select=_lib.SELECT_STATIC,
+                                  rays=tables.get(first[3], first[2], H, W, s))  # one table, as the reference builds it once
             parts.append(c.points[:c.n()].clone())
         local = torch.cat(parts, dim=0) if parts else torch.zeros((0, 4), device=device)
         allpts, _ = allgather_clouds(dist, local, local.shape[0], world, device)

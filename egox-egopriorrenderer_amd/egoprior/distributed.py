@@ -103,9 +103,17 @@ def main_distributed(argv=None):
     E = eng.Engine(device)
     rv._ENGINE = E
     artifact = rv._first_artifact(args.input_dir)
-    frames = list(rv._frames(artifact, tolerant=True))  # (c2w, rgb, intr, type, depth, mask) per frame
-    n_frames = len(frames)
+    from .io import read_pose_artifacts
+    n_frames = len(read_pose_artifacts(artifact.pose_path)[0])
     mine = shard_range(n_frames, rank, world)
+    to_render = list(range(args.start_frame, args.end_frame + 1))
+    my_slots = shard_range(len(to_render), rank, world)
+    # this rank decodes the depth maps and masks of its own frames only (and keeps only their colour images)
+    need = set(mine) | {slot for slot in my_slots if slot < n_frames}
+    frames = []  # (c2w, rgb, intr, type, depth, mask) per frame; depth = mask = io.SKIPPED for other ranks' frames
+    for i, item in enumerate(rv._frames(artifact, tolerant=True, wanted=need)):
+        frames.append(item if (i in need or i == 0) else (item[0], None, item[2], item[3], item[4], item[5]))
+    n_frames = len(frames)
     s = 2
     # ---- static cloud ---------------------------------------------------------------------------------------------
     first = next((f for f in frames if f[4] is not None), frames[0])  # first usable frame: its intrinsics and camera
@@ -143,8 +151,6 @@ def main_distributed(argv=None):
         bg.count.fill_(allpts.shape[0])
         bg.flags.fill_(1)
     # ---- my frames ------------------------------------------------------------------------------------------------
-    to_render = list(range(args.start_frame, args.end_frame + 1))
-    my_slots = shard_range(len(to_render), rank, world)
     size = (448, 448)
     rad = tan = thin = foc = pp = None
     if args.fish_eye_rendering:

@@ -78,8 +78,20 @@ def _twin(path: Path) -> Path:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def _decode_ahead(z: zipfile.ZipFile, names, decode, workers: Optional[int] = None):
-    """Yields (name, decode(bytes of the member)) in the order of `names`.  The members are read from the archive one
+class _Skipped:
+    """Stands for a frame the caller did not ask for (see `wanted` of the readers)."""
+
+
+SKIPPED = _Skipped()
+
+
+def _frame_index(name: str) -> int:
+    return int(name.split(".")[0])
+
+
+def _decode_ahead(z: zipfile.ZipFile, names, decode, workers: Optional[int] = None, wanted=None):
+    """Yields (name, decode(bytes of the member)) in the order of `names`; members whose frame index is not in `wanted`
+    (when given) are neither read nor decoded and yield SKIPPED.  The members are read from the archive one
     after the other (the archive object is not thread-safe) and decoded by a few worker threads, a bounded number of
     frames ahead of the consumer: inflate and the large numpy operations of the built-in decoders release the GIL, so
     a 1080p clip decodes several times faster than frame by frame.  An exception raised by `decode` is delivered in
@@ -98,13 +110,16 @@ def _decode_ahead(z: zipfile.ZipFile, names, decode, workers: Optional[int] = No
     with ThreadPoolExecutor(max_workers=workers) as pool:
         ahead = deque()
         for name in names:
-            ahead.append((name, pool.submit(guarded, z.read(name))))
+            if wanted is not None and _frame_index(name) not in wanted:
+                ahead.append((name, None))
+            else:
+                ahead.append((name, pool.submit(guarded, z.read(name))))
             if len(ahead) > 2 * workers:
                 n, fut = ahead.popleft()
-                yield n, fut.result()
+                yield n, (SKIPPED if fut is None else fut.result())
         while ahead:
             n, fut = ahead.popleft()
-            yield n, fut.result()
+            yield n, (SKIPPED if fut is None else fut.result())
 
 
 def read_pose_artifacts(npz_file_path: Path):
@@ -150,10 +165,11 @@ def read_rgb_artifacts(rgb_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
         yield i, np.asarray(arr[i], dtype=np.uint8)
 
 
-def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterator[tuple[int, np.ndarray]]:
+def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False, wanted=None) -> Iterator[tuple[int, np.ndarray]]:
     """Yields (frame index, (H,W) float32 metric depth).  EXR channel Z is HALF; a frame that fails to load yields NaN.
     keep_half: hand float16 data on as float16 (half the upload; the GPU kernels widen it, which is exact) instead of
-    widening it here as vipe/utils/io.py:277 does."""
+    widening it here as vipe/utils/io.py:277 does.  wanted: a container of frame indices; the other frames are not
+    decoded and yield SKIPPED in place of the array (a rank of a multi-GPU run only needs its own block)."""
     zip_file_path = Path(zip_file_path)
     if zip_file_path.exists():
         try:
@@ -164,8 +180,11 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
         with zipfile.ZipFile(zip_file_path, "r") as z:
             names = sorted(z.namelist())
             if OpenEXR is None:
-                for name, half in _decode_ahead(z, names, decode_exr_half_z):
+                for name, half in _decode_ahead(z, names, decode_exr_half_z, wanted=wanted):
                     idx = int(name.split(".")[0])
+                    if half is SKIPPED:
+                        yield idx, SKIPPED
+                        continue
                     if isinstance(half, OSError):
                         assert vw > 0 and vh > 0
                         yield idx, np.full((vh, vw), np.nan, dtype=np.float32)
@@ -177,6 +196,9 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
                 return
             for name in names:
                 idx = int(name.split(".")[0])
+                if wanted is not None and idx not in wanted:
+                    yield idx, SKIPPED
+                    continue
                 with z.open(name) as f:
                     try:
                         exr = OpenEXR.InputFile(f)
@@ -194,6 +216,9 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False) -> Iterat
         raise FileNotFoundError(str(zip_file_path))
     arr = np.load(tw, mmap_mode="r")
     for i in range(arr.shape[0]):
+        if wanted is not None and i not in wanted:
+            yield i, SKIPPED
+            continue
         a = np.asarray(arr[i])
         yield i, (a.copy() if (keep_half and a.dtype == np.float16) else a.astype(np.float32))
 
@@ -408,7 +433,7 @@ def decode_png_gray(buf: bytes) -> np.ndarray:
     return out
 
 
-def read_instance_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
+def read_instance_artifacts(zip_file_path: Path, wanted=None) -> Iterator[tuple[int, np.ndarray]]:
     """Yields (frame index, (H,W) uint8 instance ids), 0 = background."""
     zip_file_path = Path(zip_file_path)
     if zip_file_path.exists():
@@ -422,7 +447,10 @@ def read_instance_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarr
             return decode_png_gray(data).astype(np.uint8)
 
         with zipfile.ZipFile(zip_file_path, "r") as z:
-            for name, m in _decode_ahead(z, sorted(z.namelist()), decode):
+            for name, m in _decode_ahead(z, sorted(z.namelist()), decode, wanted=wanted):
+                if m is SKIPPED:
+                    yield int(name.split(".")[0]), SKIPPED
+                    continue
                 if isinstance(m, Exception):
                     raise m
                 yield int(name.split(".")[0]), m
@@ -432,7 +460,7 @@ def read_instance_artifacts(zip_file_path: Path) -> Iterator[tuple[int, np.ndarr
         raise FileNotFoundError(str(zip_file_path))
     arr = np.load(tw, mmap_mode="r")
     for i in range(arr.shape[0]):
-        yield i, np.asarray(arr[i], dtype=np.uint8)
+        yield i, (SKIPPED if (wanted is not None and i not in wanted) else np.asarray(arr[i], dtype=np.uint8))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

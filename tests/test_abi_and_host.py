@@ -379,3 +379,30 @@ def test_builtin_png_decoder_undoes_every_filter_type(dtype, filters):
     from egoprior import io as eio
     img = np.random.default_rng(len(filters)).integers(0, np.iinfo(dtype).max, size=(23, 31)).astype(dtype)
     assert np.array_equal(eio.decode_png_gray(_png_with_filters(img, filters)), img)
+
+
+@pytest.mark.parametrize("as_exr", [True, False])
+def test_readers_skip_the_frames_nobody_asked_for(tmp_path, as_exr):
+    """A rank of a multi-GPU run passes the frame indices of its block: the other frames come back as io.SKIPPED in
+    their place, undecoded (a broken member outside the block is never looked at)."""
+    import zipfile
+    from egoprior import io as eio
+    rng = np.random.default_rng(2)
+    F = 7
+    depth = (rng.random((F, 10, 14)) * 5).astype(np.float16)
+    mask = rng.integers(0, 3, size=(F, 10, 14)).astype(np.uint8)
+    rgb = rng.integers(0, 255, size=(F, 10, 14, 3)).astype(np.uint8)
+    art = eio.write_synthetic_artifacts(tmp_path / "clip", "exo", depth, rgb, mask, [10.0, 10.0, 7.0, 5.0],
+                                        np.eye(4, dtype=np.float32), depth_as_exr_zip=as_exr)
+    if as_exr:  # damage a member outside the wanted block
+        with zipfile.ZipFile(art.depth_path, "a") as z:
+            z.writestr("00009.exr", b"broken")
+    wanted = {2, 3, 5}
+    got_d = list(eio.read_depth_artifacts(art.depth_path, keep_half=True, wanted=wanted))
+    got_m = list(eio.read_instance_artifacts(art.mask_path, wanted=wanted))
+    assert [i for i, _ in got_m] == list(range(F))
+    for i, d in got_d[:F]:
+        if i in wanted:
+            assert np.array_equal(d, depth[i]) and np.array_equal(got_m[i][1], mask[i])
+        else:
+            assert d is eio.SKIPPED and got_m[i][1] is eio.SKIPPED

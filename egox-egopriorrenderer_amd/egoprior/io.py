@@ -6,7 +6,8 @@ read_pose_artifacts :169-171, read_intrinsics_artifacts :221-234, read_rgb_artif
 OpenCV:
 
   * every artifact also has an array twin that needs no codec: rgb/<name>.npy (F,H,W,3) uint8, depth/<name>.npy (F,H,W)
-    float16 or float32, mask/<name>.npy (F,H,W) uint8.  The twin is used when the codec file is absent; synthetic
+    float16 or float32 (or the per-frame files depth/<name>/depth_%06d.npy of scripts/convert_depth_zip_to_npy.py),
+    mask/<name>.npy (F,H,W) uint8.  The twin is used when the codec file is absent; synthetic
     sequences are written this way (write_synthetic_artifacts).
   * instance-mask PNGs are decoded by a small pure-Python decoder (8/16-bit greyscale, non-interlaced) when OpenCV is
     missing, and depth EXRs by a built-in reader of the subset ViPE writes (single-part scan-line file, HALF channel Z,
@@ -213,7 +214,19 @@ def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False, wanted=No
         return
     tw = _twin(zip_file_path)
     if not tw.exists():
-        raise FileNotFoundError(str(zip_file_path))
+        # per-frame arrays as scripts/convert_depth_zip_to_npy.py:108-164 writes them: <zip stem>/depth_%06d.npy, float32
+        frame_dir = zip_file_path.with_suffix("")
+        files = sorted(frame_dir.glob("depth_*.npy")) if frame_dir.is_dir() else []
+        if not files:
+            raise FileNotFoundError(str(zip_file_path))
+        for f in files:
+            i = int(f.stem.split("_")[-1])
+            if wanted is not None and i not in wanted:
+                yield i, SKIPPED
+                continue
+            a = np.load(f)
+            yield i, (a.copy() if (keep_half and a.dtype == np.float16) else a.astype(np.float32))
+        return
     arr = np.load(tw, mmap_mode="r")
     for i in range(arr.shape[0]):
         if wanted is not None and i not in wanted:

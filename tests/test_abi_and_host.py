@@ -406,3 +406,22 @@ def test_readers_skip_the_frames_nobody_asked_for(tmp_path, as_exr):
             assert np.array_equal(d, depth[i]) and np.array_equal(got_m[i][1], mask[i])
         else:
             assert d is eio.SKIPPED and got_m[i][1] is eio.SKIPPED
+
+
+def test_depth_from_the_converter_output_directory(tmp_path):
+    """scripts/convert_depth_zip_to_npy.py:108-164 turns depth/<name>.zip into <name>/depth_%06d.npy (float32): such a
+    directory next to where the zip would be is read in frame order."""
+    from egoprior import io as eio
+    rng = np.random.default_rng(4)
+    frames = (rng.random((5, 6, 8)) * 3).astype(np.float32)
+    d = tmp_path / "depth" / "clip"
+    d.mkdir(parents=True)
+    for i in (3, 0, 4, 1, 2):
+        np.save(d / f"depth_{i:06d}.npy", frames[i])
+    got = list(eio.read_depth_artifacts(tmp_path / "depth" / "clip.zip"))
+    assert [i for i, _ in got] == [0, 1, 2, 3, 4]
+    assert all(a.dtype == np.float32 and np.array_equal(a, frames[i]) for i, a in got)
+    some = list(eio.read_depth_artifacts(tmp_path / "depth" / "clip.zip", wanted={1, 4}))
+    assert some[0][1] is eio.SKIPPED and np.array_equal(some[4][1], frames[4])
+    with pytest.raises(FileNotFoundError):
+        list(eio.read_depth_artifacts(tmp_path / "depth" / "other.zip"))

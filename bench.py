@@ -390,7 +390,8 @@ def run(args):
                     "frac": k["frac_hbm"], "traffic": None, "avg_us": k["avg_us"],
                     "note": "the splat kernel is bound by VALU/LDS work (exact top-20 per pixel), not by HBM; its "
                             "algorithmic bytes are 16 B per projected point + 3 B per output pixel; `traffic` is the "
-                            "PMC figure of profiles/pmc_traffic.json (its tile lists are 16 B per point-tile pair)"}
+                            "PMC figure of profiles/pmc_traffic.json: the tile lists (16 B per point-tile pair, 2.56 "
+                            "tiles per point on average) plus the compositor's gathers of the winners' colour records"}
         tr = ROOT / "profiles" / "pmc_traffic.json"
         if tr.exists():
             try:

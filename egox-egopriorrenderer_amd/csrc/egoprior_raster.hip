@@ -4,7 +4,8 @@
 //   k_project_count : world point -> view -> NDC (pinhole or fisheye), conservative tile rectangle, wave-aggregated
 //                     per-tile counts                                        [HBM-bound: 16 B in, 16 B out per point]
 //   k_tile_scan     : exclusive scan of the tile counts (one workgroup)
-//   k_tile_fill     : same rectangle, slots reserved per run of lanes, writes the 16-byte tile-list entries
+//   k_tile_fill     : same rectangle, slots reserved per run of lanes, writes the tile-list entries (8 bytes: point
+//                     index and depth bits, for the default splat kernel; 16 bytes with NDC x, y for the others)
 //   k_splat_sweep   : one wave per 8x8 tile, one lane per pixel; buckets the tile's points by key in LDS, sweeps them
 //                     front to back keeping each pixel's K smallest (depth-bits, index) keys, then composites and
 //                     writes the uint8 frame (and, on request, pytorch3d's idx / zbuf / dists)
@@ -113,7 +114,7 @@ __device__ __forceinline__ void count_point_global(bool live, int tx0, int tx1, 
 __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                                       uint32_t* __restrict__ cursor,
                                                       const uint32_t* __restrict__ tile_start, uint4* __restrict__ list,
-                                                      uint32_t capacity, uint4 entry) {
+                                                      uint32_t capacity, uint4 entry, int list8 = 0) {
     const int lane = lane_id();
     const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
     if (!live) return;
@@ -124,7 +125,12 @@ __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx
             if (r.head) slot0 = tile_start[t] + atomicAdd(&cursor[t], r.len);
             // all lanes of a run walk the same rectangle, so the head is in this iteration too
             const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
-            if (slot < capacity) list[slot] = entry;
+            if (slot < capacity) {
+                if (list8)  // index + depth bits only; the splat kernel fetches x, y from the NDC records
+                    reinterpret_cast<uint2*>(list)[slot] = make_uint2(entry.x, entry.y);
+                else
+                    list[slot] = entry;
+            }
         }
     }
 }
@@ -293,7 +299,7 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
                                                    uint32_t* __restrict__ tile_cursor, uint4* __restrict__ list,
-                                                   uint32_t capacity) {
+                                                   uint32_t capacity, int list8) {
     const int64_t n = live_count(d_n, cap);
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
@@ -313,7 +319,7 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
             const float oz = pin[k].z;
             const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
                                            __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
-            bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
+            bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry, list8);
         }
     }
 }
@@ -565,7 +571,7 @@ __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
 }
 
-template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false, bool ROWBCAST = true>
+template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false, bool ROWBCAST = true, bool LIST8 = false>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -632,7 +638,22 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         for (int u = 0; u < RPL; ++u) {
             const uint32_t e = pos + (uint32_t)(u * 64 + lane);
             val[u] = e < end;
-            rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
+            if (LIST8) {
+                const uint2 e2 = reinterpret_cast<const uint2*>(list)[val[u] ? e : end - 1u];
+                rec[u] = make_uint4(e2.x, e2.y, 0u, 0u);
+            } else {
+                rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
+            }
+        }
+        if (LIST8) {
+            // second round trip: x, y of the entries that pass the threshold (the others read record 0)
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const bool want = val[u] && (make_key(rec[u].y, rec[u].x) < T);
+                const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? rec[u].x : 0u].x);
+                rec[u].z = __float_as_uint(xy.x);
+                rec[u].w = __float_as_uint(xy.y);
+            }
         }
         u64 kmin = ~0ull, kmax = 0ull;
         int m = 0;
@@ -1255,7 +1276,8 @@ struct RasterWs {
     uint32_t* tile_cursor;  // n_tiles
     uint32_t* tile_order;   // n_tiles
     int32_t* total;         // 1 (+ padding)
-    uint4* list;            // capacity records (point index, depth bits, NDC x, NDC y)
+    uint4* list;            // capacity slots of 16 bytes: (point index, depth bits, NDC x, NDC y), or 8-byte entries
+                            // (point index, depth bits) packed at the front
     uint64_t capacity;
     size_t header_bytes;
 };
@@ -1345,12 +1367,17 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
+    // the default splat kernel takes 8-byte list entries (index + depth bits) and fetches x, y from the NDC records once an
+    // entry has passed the threshold filter; the other variants keep the self-contained 16-byte entries
+    const int variant = ep_host::option("splat_variant");
+    const bool named = (variant >= 1 && variant <= 4) || variant == 6 || variant == 7 || (variant >= 10 && variant <= 16);
+    const int list8 = named ? 0 : 1;  // every value without a case of its own below selects the default kernel
     EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
-              w.tile_cursor, w.list, (uint32_t)w.capacity);
+              w.tile_cursor, w.list, (uint32_t)w.capacity, list8);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
     EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
               w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
-    switch (ep_host::option("splat_variant")) {
+    switch (variant) {
         case 1:
             EP_LAUNCH("k_splat_bubble", ep::k_splat_bubble, dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc, w.tile_start,
                       w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
@@ -1360,6 +1387,9 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             break;
         case 3:  // larger chunks: faster for a frame on its own, slower with several frames in flight
             EP_SWEEP(1024, 1024, 2);
+            break;
+        case 7:  // the default geometry with 16-byte list entries (kept for comparison)
+            EP_SWEEP(512, 512, 3);
             break;
         case 4:  // record coordinates as LDS broadcast reads instead of DPP row broadcasts (kept for comparison)
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
@@ -1397,8 +1427,9 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
                       w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
-        default:  // 512-record chunks: 151 VGPRs and 10.6 KiB of LDS per wave, three waves per SIMD
-            EP_SWEEP(512, 512, 3);
+        default:  // 512-record chunks, 10.6 KiB of LDS per wave, three waves per SIMD; 8-byte list entries
+            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, true, true>), dim3(n_tiles), dim3(64), 0, s, g,
+                      *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
     }
 #undef EP_SWEEP
     return ep_host::check_launch("rasterize");

@@ -185,7 +185,8 @@ def test_project_points(engine, size):
     assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 6], ids=["sweep512", "bubble", "sweep64", "sweep1024", "sweep1024-sampled"])
+@pytest.fixture(params=[0, 1, 2, 3, 6, 7],
+                ids=["sweep512-list8", "bubble", "sweep64", "sweep1024", "sweep1024-sampled", "sweep512-list16"])
 def splat_variant(request):
     """Every splat kernel variant must give the same bits: the default sweep kernel (512-record chunks), the plain
     register-insertion kernel, the sweep kernel with 64-record chunks (forces its multi-chunk merge on these small

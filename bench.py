@@ -372,6 +372,7 @@ def run(args):
         "k_project_count": 32 * n_in_avg,
         "k_tile_scan": 0,
         "k_tile_fill": 16 * n_in_avg,
+        "k_tile_fill_pieces": 16 * n_in_avg,
         "k_splat_sweep": 16 * n_avg + 3 * He * We,
         "k_splat_bubble": 16 * n_avg + 3 * He * We,
     }

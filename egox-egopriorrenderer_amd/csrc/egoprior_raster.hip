@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                                                        const egoprior_point* __restrict__ b, int64_t cap_b,
                                                        const int32_t* __restrict__ d_n_b,
                                                        egoprior_point* __restrict__ out, int32_t* __restrict__ d_total,
-                                                       uint32_t* __restrict__ tile_count, int do_count) {
+                                                       uint32_t* __restrict__ tile_count, int do_count,
+                                                       uint32_t* __restrict__ wg_piece) {
     extern __shared__ uint32_t hist[];
     const int n_tiles = g.tiles_x * g.tiles_y;
     const int64_t na = live_count(d_n_a, cap_a);
@@ -204,10 +205,19 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
     }
     if (LDS_AGG && do_count) {
         __syncthreads();
+        // wg_piece (optional): the value the atomic returns is where this workgroup's entries start inside the tile's list;
+        // k_tile_fill_pieces, which sends the same points through the same workgroups, picks it up from there
+        uint32_t* const mine = (wg_piece != nullptr) ? wg_piece + (size_t)blockIdx.x * (size_t)n_tiles : nullptr;
         for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
             const uint32_t c = hist[w];
-            if ((c & 0xFFFFu) != 0u) atomicAdd(&tile_count[2 * w], c & 0xFFFFu);
-            if ((c >> 16) != 0u) atomicAdd(&tile_count[2 * w + 1], c >> 16);
+            if ((c & 0xFFFFu) != 0u) {
+                const uint32_t b = atomicAdd(&tile_count[2 * w], c & 0xFFFFu);
+                if (mine != nullptr) mine[2 * w] = b;
+            }
+            if ((c >> 16) != 0u) {
+                const uint32_t b = atomicAdd(&tile_count[2 * w + 1], c >> 16);
+                if (mine != nullptr) mine[2 * w + 1] = b;
+            }
         }
     }
 }
@@ -320,6 +330,61 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
             const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
                                            __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
             bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry, list8);
+        }
+    }
+}
+
+// The fill pass without global atomics, for 8-byte entries.  The counting pass added every workgroup's per-tile counts to
+// the global counters and kept what those atomics returned (wg_piece): that is where the workgroup's entries start
+// inside each tile's list.  The same grid over the same points runs here, so a workgroup only has to hand out the slots
+// inside its own pieces, which it does with returning LDS atomics on 16-bit cursors (two per word, as in the counting
+// pass).  List order still depends on which workgroup's flush reached a counter first, the selection does not.
+__global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const egoprior_point* __restrict__ ndc,
+                                                          int64_t cap, const int32_t* __restrict__ d_n,
+                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint32_t* __restrict__ wg_piece,
+                                                          uint2* __restrict__ list, uint32_t capacity) {
+    extern __shared__ uint32_t cur[];
+    const int n_tiles = g.tiles_x * g.tiles_y;
+    const int n_words = (n_tiles + 1) >> 1;
+    const int64_t n = live_count(d_n, cap);
+    if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;
+    for (int w = threadIdx.x; w < n_words; w += 256) cur[w] = 0u;
+    __syncthreads();
+    const uint32_t* const mine = wg_piece + (size_t)blockIdx.x * (size_t)n_tiles;
+    const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
+    const int lane = lane_id();
+    for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
+        egoprior_point pin[EP_BIN_PPT];
+#pragma unroll
+        for (int k = 0; k < EP_BIN_PPT; ++k) {
+            int64_t i = base + k * 256 + threadIdx.x;
+            i = i < n ? i : n - 1;
+            pin[k] = ndc[i];
+        }
+#pragma unroll
+        for (int k = 0; k < EP_BIN_PPT; ++k) {
+            const int64_t i = base + k * 256 + threadIdx.x;
+            int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+            const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
+            const float oz = pin[k].z;
+            const uint2 entry = make_uint2((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz));
+            const LaneRun r = lane_runs(hit, tx0, tx1, ty0, ty1);
+            if (!hit) continue;
+            for (int ty = ty0; ty <= ty1; ++ty) {
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const int t = ty * g.tiles_x + tx;
+                    uint32_t slot0 = 0u;
+                    if (r.head) {
+                        const uint32_t sh = (uint32_t)(t & 1) * 16u;
+                        const uint32_t pos = (atomicAdd(&cur[t >> 1], r.len << sh) >> sh) & 0xFFFFu;
+                        slot0 = tile_start[t] + mine[t] + pos;
+                    }
+                    // all lanes of a run walk the same rectangle, so the head is in this iteration too
+                    const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
+                    if (slot < capacity) list[slot] = entry;
+                }
+            }
         }
     }
 }
@@ -1328,6 +1393,18 @@ int grid_for(int64_t n, int block) {
     return (int)b;
 }
 
+// Where the counting pass leaves every workgroup's list offsets for k_tile_fill_pieces: in the upper half of the list
+// slots, which the 8-byte entries of the default splat kernel never reach.  NULL when that variant is not in use, when
+// the counting pass does not aggregate in LDS, or when the table (workgroups x tiles words) does not fit there.
+uint32_t* pieces_table(const RasterWs& w, int n_tiles, int64_t n) {
+    const int variant = ep_host::option("splat_variant");
+    const bool named = (variant >= 1 && variant <= 4) || variant == 6 || variant == 7 || (variant >= 10 && variant <= 16);
+    if (named || ep_host::option("fill_pieces") == 0 || !lds_agg_ok(n_tiles, n)) return nullptr;
+    const uint64_t need = (uint64_t)bin_grid(n) * (uint64_t)n_tiles * sizeof(uint32_t);
+    if (need > (uint64_t)w.capacity * 8ull) return nullptr;
+    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w.list) + (size_t)w.capacity * 8);
+}
+
 int check_raster_args(const egoprior_raster_params* rp, int H, int W, int64_t n) {
     if (rp == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "raster params is NULL");
     if (H <= 0 || W <= 0 || H > 16384 || W > 16384) return ep_host::fail(EGOPRIOR_E_INVALID, "image size out of range");
@@ -1372,8 +1449,13 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int variant = ep_host::option("splat_variant");
     const bool named = (variant >= 1 && variant <= 4) || variant == 6 || variant == 7 || (variant >= 10 && variant <= 16);
     const int list8 = named ? 0 : 1;  // every value without a case of its own below selects the default kernel
-    EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
-              w.tile_cursor, w.list, (uint32_t)w.capacity, list8);
+    uint32_t* const pieces = pieces_table(w, n_tiles, n);
+    if (pieces != nullptr)
+        EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
+                  d_ndc, n, d_n, w.tile_start, pieces, reinterpret_cast<uint2*>(w.list), (uint32_t)w.capacity);
+    else
+        EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
+                  w.tile_cursor, w.list, (uint32_t)w.capacity, list8);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
     EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
               w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
@@ -1463,7 +1545,7 @@ extern "C" int egoprior_project_points(const egoprior_camera* cam, const egoprio
     ep::RasterGeom g = make_geom(cam->H > 0 ? cam->H : 1, cam->W > 0 ? cam->W : 1, 1e-3f);
     EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n_a + n_b)), dim3(256), 0,
               (hipStream_t)stream, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
-              (int32_t*)nullptr, (uint32_t*)nullptr, 0);
+              (int32_t*)nullptr, (uint32_t*)nullptr, 0, (uint32_t*)nullptr);
     return ep_host::check_launch("project_points");
 }
 
@@ -1491,11 +1573,12 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if (lds_agg_ok(n_tiles, n))
         EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256),
                   bin_lds_bytes(n_tiles), s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
-                  (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1);
+                  (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1,
+                  pieces_table(w, n_tiles, n));
     else
         EP_LAUNCH("k_project_count", (ep::k_project_count<false, false>), dim3(bin_grid(n)), dim3(256), 0, s,
                   cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr, (int64_t)0, (const int32_t*)nullptr,
-                  (egoprior_point*)nullptr, w.total, w.tile_count, 1);
+                  (egoprior_point*)nullptr, w.total, w.tile_count, 1, (uint32_t*)nullptr);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, d_n, d_flags_a, d_flags_b, w, out, d_status, s);
 }
@@ -1533,10 +1616,10 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
     if (lds_agg_ok(n_tiles, n))
         EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256),
                   bin_lds_bytes(n_tiles), s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
-                  w.total, w.tile_count, 1);
+                  w.total, w.tile_count, 1, pieces_table(w, n_tiles, n));
     else
         EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n)), dim3(256), 0, s, *cam, g,
-                  d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1);
+                  d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1, (uint32_t*)nullptr);
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
     return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);
 }

@@ -346,7 +346,7 @@ def run(args):
     # ---- per-kernel timing with HIP events (separate pass, same frames) ---------------------------------------------
     kern = {}
     if rank == 0:
-        n_prof = min(args.steps, 50)
+        n_prof = args.steps  # the same frames as the timed region (their cost varies along the ego orbit)
         torch.cuda.synchronize()
         _lib.profile_begin()  # every kernel bracketed by HIP events; one stream, so nothing overlaps the timed kernel
         for i in range(n_prof):

@@ -212,7 +212,9 @@ int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32
 int egoprior_profile_begin(void);
 /* Process-wide tuning / test switches (no counterpart in the reference): "splat_variant" (0 default sweep kernel with
  * 512-record chunks, 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks to force its multi-chunk
- * path on small inputs, 3 with 1024-record chunks, 6 with sampled bucket boundaries), "bin_lds" (1 default: the tile
+ * path on small inputs, 3 with 1024-record chunks, 6 with sampled bucket boundaries), "fill_pieces" (1 default: the
+ * tile lists are filled without global atomics where the counting pass could leave its per-workgroup offsets, 0: always
+ * one reservation per run of lanes), "bin_lds" (1 default: the tile
  * counts are aggregated per workgroup in LDS, 0: straight global atomics). */
 int egoprior_set_option(const char* name, int32_t value);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,

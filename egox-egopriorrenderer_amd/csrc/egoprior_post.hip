@@ -1,7 +1,10 @@
 // Output-side helper for gfx950: the white-pixel metric the batch scripts compute on the dumped frames
 // (data_preprocess/scripts/postprocess_render_dir.py:17-31, 46-67), evaluated on the frames while they are still in HBM.
-//   gray = float32(0.299 * r + 0.587 * g + 0.114 * b)   (float64 products and sums, left to right, as numpy does)
-//   mask = gray >= threshold ;  per frame: number of mask pixels
+//   gray = PIL's Image.convert("L"): (19595 r + 38470 g + 7471 b + 0x8000) >> 16, an integer in 0..255  (:17-19, the branch
+//          the script takes whenever PIL imports, and pillow is pinned in the reference's envs/requirements.txt)
+//       or float32(0.299 * r + 0.587 * g + 0.114 * b)   (:20-25, the imageio fallback; float64 products and sums, left to
+//          right, as numpy does)
+//   mask = float32(gray) >= threshold ;  per frame: number of mask pixels
 #include "egoprior_common.h"
 #include "egoprior_host.h"
 
@@ -10,8 +13,8 @@ namespace ep {
 // One workgroup takes 1024 consecutive pixels of one frame (4 per thread); counts go to counts[frame] with one atomic
 // per workgroup.  HBM-bound: 3 bytes in per pixel, 1 byte out when the mask image is asked for.
 __global__ void __launch_bounds__(256) k_white_pixels(const uint8_t* __restrict__ frames, int64_t pixels_per_frame,
-                                                      float threshold, int32_t* __restrict__ counts,
-                                                      uint8_t* __restrict__ masks) {
+                                                      float threshold, int grey_rule,
+                                                      int32_t* __restrict__ counts, uint8_t* __restrict__ masks) {
     __shared__ uint32_t ws[4];
     const int64_t f = blockIdx.y;
     const int64_t p0 = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;
@@ -21,8 +24,14 @@ __global__ void __launch_bounds__(256) k_white_pixels(const uint8_t* __restrict_
     for (int k = 0; k < 4; ++k) {
         const int64_t p = p0 + k;
         if (p < pixels_per_frame) {
-            const double r = (double)src[p * 3 + 0], g = (double)src[p * 3 + 1], b = (double)src[p * 3 + 2];
-            const float gray = (float)((0.299 * r + 0.587 * g) + 0.114 * b);
+            const uint32_t ri = src[p * 3 + 0], gi = src[p * 3 + 1], bi = src[p * 3 + 2];
+            float gray;
+            if (grey_rule == EGOPRIOR_GREY_PIL_L) {
+                gray = (float)((ri * 19595u + gi * 38470u + bi * 7471u + 0x8000u) >> 16);
+            } else {
+                const double r = (double)ri, g = (double)gi, b = (double)bi;
+                gray = (float)((0.299 * r + 0.587 * g) + 0.114 * b);
+            }
             const bool on = gray >= threshold;
             c += on ? 1u : 0u;
             if (masks != nullptr) masks[f * pixels_per_frame + p] = on ? 255 : 0;
@@ -41,9 +50,12 @@ __global__ void __launch_bounds__(256) k_white_pixels(const uint8_t* __restrict_
 }  // namespace ep
 
 extern "C" int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32_t H, int32_t W,
-                                           float threshold, int32_t* d_counts, uint8_t* d_masks, void* stream) {
+                                           float threshold, int32_t grey_rule, int32_t* d_counts, uint8_t* d_masks,
+                                           void* stream) {
     if (d_frames == nullptr || d_counts == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
     if (n_frames < 0 || H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    if (grey_rule != EGOPRIOR_GREY_PIL_L && grey_rule != EGOPRIOR_GREY_FLOAT)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "unknown grey rule");
     if (n_frames == 0) return 0;
     if (n_frames > 65535) return ep_host::fail(EGOPRIOR_E_UNSUPPORTED, "more than 65535 frames per call");
     hipStream_t s = (hipStream_t)stream;
@@ -51,6 +63,6 @@ extern "C" int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_fr
         return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     const int64_t ppf = (int64_t)H * W;
     EP_LAUNCH("k_white_pixels", ep::k_white_pixels, dim3((unsigned)((ppf + 1023) / 1024), (unsigned)n_frames), dim3(256),
-              0, s, d_frames, ppf, threshold, d_counts, d_masks);
+              0, s, d_frames, ppf, threshold, (int)grey_rule, d_counts, d_masks);
     return ep_host::check_launch("white_pixel_counts");
 }

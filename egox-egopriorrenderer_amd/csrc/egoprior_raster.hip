@@ -181,6 +181,11 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                 const egoprior_point p = (i < na) ? a[i] : b[i - na];
                 if (PROJECT) {
                     project_point(cam, p.x, p.y, p.z, ox, oy, oz);
+                    // The render-entry filters of the reference (finite coordinates, |p| < 1e6 with the float32 norm
+                    // sqrt((x*x + y*y) + z*z), scripts/render_vipe_pointcloud.py:807-821) for clouds that did not pass
+                    // through egoprior_filter_cloud: sqrtf(s) < 1e6f exactly when s < float32(1e12), and a non-finite
+                    // coordinate makes s infinite or NaN.  A point that fails is never drawn (it keeps its index).
+                    if (do_count && !(((p.x * p.x + p.y * p.y) + p.z * p.z) < 999999995904.0f)) oz = -1.0f;
                     egoprior_point q;
                     q.x = ox;
                     q.y = oy;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     }
     if (tid == 0) {
         tile_start[n_tiles] = carry_s;
-        if (d_status != nullptr) *d_status = (carry_s > capacity) ? 1 : 0;
+        if (d_status != nullptr && carry_s > capacity) *d_status = 1;  // sticky: only the caller clears it
     }
     // exclusive scan of the 256 length classes (4 waves), then the launch order
     uint32_t c = 0, incl = 0;
@@ -1427,7 +1432,6 @@ int clear_outputs(int H, int W, int K, const ep::SplatOut& out, int32_t* d_statu
     if (out.image_u8 != nullptr) ok = ok && hipMemsetAsync(out.image_u8, 0, npix * 3, s) == hipSuccess;
     if (out.image_f32 != nullptr) ok = ok && hipMemsetAsync(out.image_f32, 0, npix * 3 * sizeof(float), s) == hipSuccess;
     if (out.idx != nullptr) ok = ok && hipMemsetAsync(out.idx, 0xFF, npix * K * sizeof(int32_t), s) == hipSuccess;
-    if (d_status != nullptr) ok = ok && hipMemsetAsync(d_status, 0, sizeof(int32_t), s) == hipSuccess;
     if (!ok) return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
     const size_t nk = npix * (size_t)K;
     if (out.zbuf != nullptr)

@@ -18,6 +18,8 @@ TILE = 8
 E_OK, E_INVALID, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
 SELECT_STATIC, SELECT_DYNAMIC, SELECT_ALL = 0, 1, 2
 CAM_PINHOLE, CAM_FISHEYE = 0, 1
+GREY_PIL_L, GREY_FLOAT = 0, 1
+ABI_VERSION = 2
 
 
 class UnprojectParams(C.Structure):
@@ -74,7 +76,7 @@ SIGNATURES = {
     "egoprior_render_workspace_bytes": (_sz, [_i32, _i32, _i64, _f32]),
     "egoprior_render_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _vp, _i64, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "egoprior_white_pixel_counts": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "egoprior_white_pixel_counts": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "egoprior_set_option": (C.c_int, [C.c_char_p, _i32]),
     "egoprior_profile_begin": (C.c_int, []),
     "egoprior_profile_end": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _i32, _vp]),
@@ -106,7 +108,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.egoprior_abi_version() != 1:
+        if L.egoprior_abi_version() != ABI_VERSION:
             raise ImportError("libegoprior_hip.so ABI version mismatch")
         _LIB = L
     return _LIB

@@ -320,10 +320,13 @@ class Engine:
         return dict(image=img, image_f32=f32, idx=idx, zbuf=zb, dists=ds, status=status)
 
     # -- output side ---------------------------------------------------------------------------------------------------
-    def white_pixel_counts(self, frames, threshold: float = 30.0, want_masks: bool = False):
-        """Per-frame count of pixels whose grey value 0.299 r + 0.587 g + 0.114 b reaches `threshold`
-        (data_preprocess/scripts/postprocess_render_dir.py:17-31, 46-67).  frames: (n, H, W, 3) uint8 (device tensor or
-        array).  Returns the int32 device tensor of counts, and the (n, H, W) 0/255 masks if asked for."""
+    def white_pixel_counts(self, frames, threshold: float = 30.0, want_masks: bool = False, grey: str = "pil"):
+        """Per-frame count of pixels whose grey value reaches `threshold`
+        (data_preprocess/scripts/postprocess_render_dir.py:17-31, 46-67).  grey="pil": PIL's Image.convert("L") integer
+        luma, the branch the script takes whenever PIL imports; grey="float": its imageio fallback,
+        float32(0.299 r + 0.587 g + 0.114 b).  frames: (n, H, W, 3) uint8 (device tensor or array).  Returns the int32
+        device tensor of counts, and the (n, H, W) 0/255 masks if asked for."""
+        rule = {"pil": _lib.GREY_PIL_L, "float": _lib.GREY_FLOAT}[grey]
         fr = self.to_device(frames, torch.uint8)
         if fr.dim() == 3:
             fr = fr[None]
@@ -333,8 +336,8 @@ class Engine:
         counts = torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
         masks = torch.empty((n, H, W), dtype=torch.uint8, device=self.device) if want_masks else None
         with torch.cuda.device(self.device):
-            check(self.L.egoprior_white_pixel_counts(_ptr(fr), n, H, W, float(threshold), _ptr(counts), _ptr(masks),
-                                                     _stream()))
+            check(self.L.egoprior_white_pixel_counts(_ptr(fr), n, H, W, float(threshold), rule, _ptr(counts),
+                                                     _ptr(masks), _stream()))
         return (counts[:n], masks) if want_masks else counts[:n]
 
     def render_frame(self, cam: Camera, rp: RasterParams, a: DeviceCloud, b: Optional[DeviceCloud] = None,
@@ -492,5 +495,7 @@ class FramePipeline:
     def finish(self) -> None:
         self.join()
         self.main.synchronize()
+        # the kernels only ever raise a slot's status word, so one word covers every frame the slot has rendered
         if int(self.status.abs().sum().item()) != 0:
+            self.status.zero_()
             raise RuntimeError("tile lists overflowed their workspace (status != 0)")

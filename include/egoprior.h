@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define EGOPRIOR_ABI_VERSION 1
+#define EGOPRIOR_ABI_VERSION 2
 #define EGOPRIOR_MAX_K 20 /* points_per_pixel the reference always uses (:861, :1073) */
 #define EGOPRIOR_TILE 8   /* binning tile edge in pixels: one 64-lane wave owns one 8x8 tile */
 
@@ -169,7 +169,8 @@ int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_
  *   d_image_f32 (H,W,3) float32                               -- compositor output before clamp / dark rule
  *   d_idx, d_zbuf, d_dists (H,W,K) int32 / f32 / f32, -1 pad  -- rasterize_points' three outputs
  * Workspace: egoprior_raster_workspace_bytes(H, W, n, radius); a frame whose tile lists outgrow it sets the int32 at
- * d_status to 1 (else 0) and drops the entries that do not fit.  The size the query returns reserves, for every point,
+ * d_status to 1 and drops the entries that do not fit.  The word is never cleared by the library (zero it before the
+ * first call), so one word can watch over many frames.  The size the query returns reserves, for every point,
  * the largest number of tiles a disc of that radius can overlap, so it cannot overflow for that n.  List positions are
  * 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused with EGOPRIOR_E_INVALID (split the cloud).
  * --------------------------------------------------------------------------------------------------------------- */
@@ -181,8 +182,11 @@ int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, in
                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * One ego frame end to end = render_points_pytorch3d (:754-890) or render_points_fisheye (:892-1102) after their
- * host-side filters: egoprior_project_points followed by egoprior_rasterize_composite, sharing one workspace.
+ * One ego frame end to end = render_points_pytorch3d (:754-890) or render_points_fisheye (:892-1102):
+ * egoprior_project_points followed by egoprior_rasterize_composite, sharing one workspace.  The reference's entry
+ * filters (:807-821: finite coordinates, float32 norm below 1e6) are applied to both parts on the fly: a point that fails
+ * them is never drawn but keeps its place in the index space (run egoprior_filter_cloud first where the index maps must
+ * count only surviving points, as the reference's do).
  * Workspace: egoprior_render_workspace_bytes(H, W, n_a + n_b, radius).
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_render_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
@@ -196,11 +200,15 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
  * White-pixel metric of finished frames, data_preprocess/scripts/postprocess_render_dir.py:17-31 (grey conversion and
  * threshold) and :46-67 (per-frame counts that the batch script sums up to pick the best camera), computed on the
  * uint8 frames where the renderer left them instead of on PNG files dumped by ffmpeg.
- * d_frames: n_frames x H x W x 3 uint8; d_counts[n_frames] receives the number of pixels with
- * float32(0.299 r + 0.587 g + 0.114 b) >= threshold; d_masks (optional, n_frames x H x W) receives 0 / 255.
+ * d_frames: n_frames x H x W x 3 uint8; d_counts[n_frames] receives the number of pixels whose grey value reaches
+ * threshold; d_masks (optional, n_frames x H x W) receives 0 / 255.  grey_rule picks the script's grey conversion:
+ * EGOPRIOR_GREY_PIL_L, its first branch (:17-19, taken whenever PIL imports; pillow is pinned in the reference's
+ * envs/requirements.txt): PIL's Image.convert("L") = (19595 r + 38470 g + 7471 b + 0x8000) >> 16;
+ * EGOPRIOR_GREY_FLOAT, its imageio fallback (:20-25): float32(0.299 r + 0.587 g + 0.114 b).
  * --------------------------------------------------------------------------------------------------------------- */
+enum { EGOPRIOR_GREY_PIL_L = 0, EGOPRIOR_GREY_FLOAT = 1 };
 int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32_t H, int32_t W, float threshold,
-                                int32_t* d_counts, uint8_t* d_masks, void* stream);
+                                int32_t grey_rule, int32_t* d_counts, uint8_t* d_masks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Per-kernel timing for benchmarks (no counterpart in the reference, which has no profiling on this path).

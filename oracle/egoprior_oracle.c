@@ -26,6 +26,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* pytorch3d rasterization_utils: pixel index -> NDC coordinate of the pixel
  * centre for a possibly non-square image.  S1 is the size of the axis being
@@ -153,26 +156,39 @@ void oracle_rasterize_points_scatter(const float* pts, float r, int64_t P, int H
     const double range_x = (W > H) ? (2.0 * W) / H : 2.0;
     const double range_y = (H > W) ? (2.0 * H) / W : 2.0;
     const double pitch_x = range_x / W, pitch_y = range_y / H;
-    for (int64_t p = 0; p < P; ++p) {
-        const float px = pts[3 * p + 0], py = pts[3 * p + 1], pz = pts[3 * p + 2];
-        if (pz < 0) continue;
-        if (!(isfinite(px) && isfinite(py))) continue; /* cannot pass dist2 < radius2 */
-        /* xf[xi] = range_x/2 - (xi + 0.5) * pitch_x  =>  xi = (range_x/2 - x)/pitch_x - 0.5 */
-        const double cx = (range_x / 2.0 - (double)px) / pitch_x - 0.5;
-        const double cy = (range_y / 2.0 - (double)py) / pitch_y - 0.5;
-        const double rx = (double)r / pitch_x + 1.0, ry = (double)r / pitch_y + 1.0; /* +1 px pad */
-        double lo_x = floor(cx - rx), hi_x = ceil(cx + rx), lo_y = floor(cy - ry), hi_y = ceil(cy + ry);
-        if (hi_x < 0 || hi_y < 0 || lo_x > W - 1 || lo_y > H - 1) continue;
-        const int x0 = lo_x < 0 ? 0 : (int)lo_x, x1 = hi_x > W - 1 ? W - 1 : (int)hi_x;
-        const int y0 = lo_y < 0 ? 0 : (int)lo_y, y1 = hi_y > H - 1 ? H - 1 : (int)hi_y;
-        for (int yi = y0; yi <= y1; ++yi) {
-            const float dy = py - yf[yi];
-            for (int xi = x0; xi <= x1; ++xi) {
-                const float dx = px - xf[xi];
-                const float dist2 = dx * dx + dy * dy;
-                if (dist2 < radius2) {
-                    const size_t pix = (size_t)yi * (size_t)W + (size_t)xi;
-                    frag_insert(q + pix * (size_t)K, &cnt[pix], K, pz, (int32_t)p, dist2);
+    /* Threads split the image into bands of rows; every thread walks all points in index order and touches only the
+     * pixels of its own band, so each pixel still sees its points in the same order as in a serial run. */
+#pragma omp parallel
+    {
+        int nt = 1, tid = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads();
+        tid = omp_get_thread_num();
+#endif
+        const int band0 = (int)(((int64_t)H * tid) / nt), band1 = (int)(((int64_t)H * (tid + 1)) / nt) - 1;
+        for (int64_t p = 0; p < P; ++p) {
+            const float px = pts[3 * p + 0], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+            if (pz < 0) continue;
+            if (!(isfinite(px) && isfinite(py))) continue; /* cannot pass dist2 < radius2 */
+            /* xf[xi] = range_x/2 - (xi + 0.5) * pitch_x  =>  xi = (range_x/2 - x)/pitch_x - 0.5 */
+            const double cx = (range_x / 2.0 - (double)px) / pitch_x - 0.5;
+            const double cy = (range_y / 2.0 - (double)py) / pitch_y - 0.5;
+            const double rx = (double)r / pitch_x + 1.0, ry = (double)r / pitch_y + 1.0; /* +1 px pad */
+            double lo_x = floor(cx - rx), hi_x = ceil(cx + rx), lo_y = floor(cy - ry), hi_y = ceil(cy + ry);
+            if (hi_x < 0 || hi_y < 0 || lo_x > W - 1 || lo_y > H - 1) continue;
+            const int x0 = lo_x < 0 ? 0 : (int)lo_x, x1 = hi_x > W - 1 ? W - 1 : (int)hi_x;
+            int y0 = lo_y < 0 ? 0 : (int)lo_y, y1 = hi_y > H - 1 ? H - 1 : (int)hi_y;
+            if (y0 < band0) y0 = band0;
+            if (y1 > band1) y1 = band1;
+            for (int yi = y0; yi <= y1; ++yi) {
+                const float dy = py - yf[yi];
+                for (int xi = x0; xi <= x1; ++xi) {
+                    const float dx = px - xf[xi];
+                    const float dist2 = dx * dx + dy * dy;
+                    if (dist2 < radius2) {
+                        const size_t pix = (size_t)yi * (size_t)W + (size_t)xi;
+                        frag_insert(q + pix * (size_t)K, &cnt[pix], K, pz, (int32_t)p, dist2);
+                    }
                 }
             }
         }

@@ -517,12 +517,24 @@ def render_points_fisheye(points_world, colors_world, T_w2c, f_px, cx_px, cy_px,
 # --------------------------------------------------------------------------------------------------------------------
 # output side: white-pixel metric
 # --------------------------------------------------------------------------------------------------------------------
-def white_pixel_mask(frame_u8, threshold: float = 30.0):
-    """data_preprocess/scripts/postprocess_render_dir.py:17-31: grey = float32(0.299 r + 0.587 g + 0.114 b) with the
-    products and sums in float64 (uint8 arrays times Python floats), mask = grey >= threshold; returns (0/1 uint8 mask,
-    0/255 uint8 picture).  :60-63: the metric is mask.sum() per frame."""
+def pil_luma(frame_u8) -> np.ndarray:
+    """PIL's Image.convert("L") on an RGB image (ITU-R 601-2 luma in 16.16 fixed point, rounded):
+    (19595 R + 38470 G + 7471 B + 0x8000) >> 16.  Pinned by tests/golden/g4_pil_luma.npz (made with PIL itself)."""
+    a = np.asarray(frame_u8).astype(np.uint32)
+    return ((a[..., 0] * 19595 + a[..., 1] * 38470 + a[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def white_pixel_mask(frame_u8, threshold: float = 30.0, grey: str = "pil"):
+    """data_preprocess/scripts/postprocess_render_dir.py:17-31.  grey="pil" (:17-19, the branch taken whenever PIL
+    imports): grey = float32(Image.convert("L")); grey="float" (:20-25, the imageio fallback):
+    grey = float32(0.299 r + 0.587 g + 0.114 b) with the products and sums in float64 (uint8 arrays times Python
+    floats).  mask = grey >= threshold; returns (0/1 uint8 mask, 0/255 uint8 picture).  :60-63: the metric is
+    mask.sum() per frame."""
     arr = np.asarray(frame_u8)
     r, g, b = arr[..., 0], arr[..., 1], arr[..., 2]
-    gray = (0.299 * r + 0.587 * g + 0.114 * b).astype(F32)
+    if grey == "pil":
+        gray = pil_luma(arr).astype(F32)
+    else:
+        gray = (0.299 * r + 0.587 * g + 0.114 * b).astype(F32)
     logical = (gray >= F32(threshold)).astype(np.uint8)
     return logical, (logical * 255).astype(np.uint8)

@@ -10,6 +10,9 @@ What is produced and from where:
                            366-387) on the pixel grid of scripts/render_vipe_pointcloud.py:384-398.
   g2_nanmean.npz ......... torch.nan_to_num(torch.nanmean(x, dim=0)) on CPU, the two calls the reference makes at
                            scripts/render_vipe_pointcloud.py:466-471.
+  g4_pil_luma.npz ........ PIL's Image.convert("L") on random RGB pixels (dark ones over-represented, every grey level
+                           around the threshold 30 present): the call data_preprocess/scripts/postprocess_render_dir.py
+                           :17-19 makes before thresholding.
   cameras_cmu_bike08_2.json  camera parameters copied from the reference's example data files
                            (data_preprocess/example/annotations/.../1410e2ce-....json: cam01 K + W2C, aria01 K and its
                            first 128 per-frame W2C; takes/cmu_bike08_2/trajectory/online_calibration.jsonl line 0,
@@ -133,6 +136,16 @@ def make_g2():
     np.savez_compressed(OUT / "g2_nanmean.npz", **out)
 
 
+def make_g4():
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    a[:48] = rng.integers(0, 80, (48, 128, 3), dtype=np.uint8)  # dark half: grey values around the threshold
+    a[0, :3] = [[30, 30, 30], [29, 30, 31], [100, 0, 2]]
+    L = np.asarray(Image.fromarray(a, "RGB").convert("L"))
+    np.savez_compressed(OUT / "g4_pil_luma.npz", rgb=a, L=L)
+
+
 def make_cameras():
     base = REF / "data_preprocess/example"
     d = json.load(open(base / "annotations/ego_pose/test/camera_pose/1410e2ce-a62c-4a2c-8453-6eb172a58965.json"))
@@ -156,5 +169,6 @@ if __name__ == "__main__":
     make_g1(cams, dep)
     make_g2()
     make_g3(cams)
+    make_g4()
     make_cameras()
     print("golden fixtures written to", OUT)

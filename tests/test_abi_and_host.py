@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} is declared in include/egoprior.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table and header disagree"
-    assert _lib.lib().egoprior_abi_version() == 1
+    assert _lib.lib().egoprior_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_argument_validation_without_gpu():

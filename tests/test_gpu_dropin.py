@@ -1,6 +1,7 @@
 """GPU: the drop-in Python surface and CLI end to end on a synthetic ViPE-format directory, against the same pipeline
 assembled from the CPU oracle."""
 import json
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -153,12 +154,19 @@ def test_white_pixel_metrics_match_the_numpy_recipe(engine, tmp_path):
     frames[2, :, :, :] = 30                         # grey exactly 30 -> counts (>=)
     frames[3, :8] = [29, 30, 31]                    # grey 29.8..: below
     frames[3, 8:16] = [100, 0, 2]                   # 0.299*100 + 0.228 = 30.128
+    for grey in ("pil", "float"):
+        counts, masks = engine.white_pixel_counts(frames, 30.0, want_masks=True, grey=grey)
+        for i in range(5):
+            logical, vis = O.white_pixel_mask(frames[i], 30.0, grey=grey)
+            assert counts[i].item() == int(logical.sum())
+            assert np.array_equal(masks[i].cpu().numpy(), vis)
+        assert counts[1].item() == 0 and counts[2].item() == 37 * 53
+    # the fixture made with PIL's own Image.convert("L"), dark pixels around the threshold
+    g = np.load(Path(__file__).parent / "golden" / "g4_pil_luma.npz")
+    c4, m4 = engine.white_pixel_counts(g["rgb"][None], 30.0, want_masks=True)
+    assert c4[0].item() == int((g["L"] >= 30).sum())
+    assert np.array_equal(m4[0].cpu().numpy(), np.where(g["L"] >= 30, 255, 0).astype(np.uint8))
     counts, masks = engine.white_pixel_counts(frames, 30.0, want_masks=True)
-    for i in range(5):
-        logical, vis = O.white_pixel_mask(frames[i], 30.0)
-        assert counts[i].item() == int(logical.sum())
-        assert np.array_equal(masks[i].cpu().numpy(), vis)
-    assert counts[1].item() == 0 and counts[2].item() == 37 * 53
     total, any_white, n = rv.dump_frames_and_metrics(list(frames), tmp_path, 30.0)
     assert (total, any_white, n) == (int(counts.sum().item()), 4, 5)
     assert np.array_equal(decode_png_gray((tmp_path / "frame_000003_mask.png").read_bytes()),

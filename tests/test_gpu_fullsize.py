@@ -197,3 +197,56 @@ def test_twenty_million_points_on_a_1024_square_image(engine):
     assert np.array_equal(res["idx"].cpu().numpy(), ref_idx)
     assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z)
     assert np.array_equal(res["dists"].cpu().numpy(), ref_d)
+
+
+def test_fiftyeight_million_points_on_a_1024_square_image(engine):
+    """BASELINE configs[4] at its real size: ~58 M points (50 M accumulated + 8 M of a 4K exo frame) on a 1024 x 1024 ego
+    image at point_size 5.  Every pixel is covered by ~3 500 discs and every tile list is dozens of chunks long.  9 tiles
+    per disc at most, so the 32-bit list positions allow 477 M points at this radius; 58 M is what the config names."""
+    from egoprior import engine as eng
+    rng = np.random.default_rng(11)
+    n, S = 58_000_000, 1024
+    ndc = np.empty((n, 3), dtype=np.float32)
+    ndc[:, 0] = rng.uniform(-1.1, 1.1, n)
+    ndc[:, 1] = rng.uniform(-1.1, 1.1, n)
+    ndc[:, 2] = rng.uniform(0.5, 50, n)
+    ndc[::4099, 2] = -0.5  # behind the camera
+    r = O.radius_ndc(5.0, S, S)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, S, S, K, "scatter")
+    rec = torch.zeros((n, 4), dtype=torch.float32, device=engine.device)
+    rec[:, :3] = torch.from_numpy(ndc).to(engine.device)
+    del ndc
+    rp = eng.make_raster_params(5.0, S, S, K=K, colors_gt1=1)
+    res = engine.rasterize_composite(rec, None, rp, S, S, want_fragments=True)
+    assert res["status"].item() == 0
+    assert np.array_equal(res["idx"].cpu().numpy(), ref_idx)
+    assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z)
+    assert np.array_equal(res["dists"].cpu().numpy(), ref_d)
+    engine._ws.pop("raster", None)  # 8 GB of tile lists: give them back
+
+
+@pytest.mark.parametrize("select", ["static", "dynamic"])
+def test_unproject_4k_exo_frame(engine, select):
+    """BASELINE configs[4]'s exo side: 3840 x 2160, subsample 1 = 8 100 compaction blocks, more than the scatter kernels
+    sum on their own (4 096), so the one-workgroup block scan runs in between.  Bit-exact float64 points, colours, order."""
+    from egoprior import _lib, synth
+    Hh, Ww = 2160, 3840
+    d, rgb, m = [t[0].numpy() for t in synth.make_frames(Hh, Ww, [3], 8)]
+    exo = synth.exo_w2c()
+    T = np.linalg.inv(exo)
+    intr = synth.exo_intrinsics(Hh, Ww)
+    c2w = np.eye(4, dtype=np.float32)
+    a = 0.05
+    c2w[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=np.float32)
+    c2w[:3, 3] = [0.05, -0.1, 0.2]
+    ref_p, ref_c = O.unproject_frame(d, rgb, m, intr, c2w, T, 1, select)
+    sel = _lib.SELECT_STATIC if select == "static" else _lib.SELECT_DYNAMIC
+    cloud = engine.unproject_frame(d, rgb, m, intr, c2w, T, subsample=1, select=sel, want_xyz64=True)
+    n = cloud.n()
+    assert n == ref_p.shape[0] and n > (1_000_000 if select == "static" else 10_000)
+    assert np.array_equal(cloud.xyz64[:n].cpu().numpy(), ref_p)
+    p32, cols = cloud.to_numpy()
+    assert np.array_equal(cols, ref_c)
+    assert np.array_equal(p32, ref_p.astype(np.float32))
+    assert cloud.flags.item() == 1
+    engine._ws.pop("unproject", None)

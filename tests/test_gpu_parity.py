@@ -521,6 +521,81 @@ def test_mean_background_matches_torch_nanmean(engine):
     assert torch.equal(mc.cpu(), ref_c)
 
 
+@pytest.mark.parametrize("F", [256, 300, 1000])
+def test_mean_background_long_clips(engine, F):
+    """Clips long enough for the upper cascade levels: ATen flushes level 0 into level 1 every 16 terms, level 1 into
+    level 2 every 256 and the tail is folded at the end; BASELINE configs[2] is 1 000 frames.  Checked against the
+    oracle's cascade and against torch.nanmean itself (the call the reference makes), bit for bit; accumulated in calls
+    of uneven length so that call boundaries fall inside runs."""
+    clip = synthetic_clip(72, 128, F)
+    ref_d, ref_c = O.mean_background(clip["depth"], clip["rgb"], clip["mask"])
+    st = engine.meanbg_new_state(72, 128)
+    cuts = [0, 7, 100, 256, 271, 513, F]
+    cuts = sorted(set(c for c in cuts if c <= F))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        engine.meanbg_accumulate(st, clip["depth"][lo:hi], clip["rgb"][lo:hi], clip["mask"][lo:hi], lo)
+    md, mc = engine.meanbg_finalize(st)
+    assert np.array_equal(md.cpu().numpy(), ref_d)
+    assert np.array_equal(mc.cpu().numpy(), np.clip(ref_c * F32(255), 0, 255).astype(np.uint8))
+    st1 = engine.meanbg_new_state(72, 128)
+    engine.meanbg_accumulate(st1, clip["depth"], clip["rgb"], clip["mask"], 0)  # one call for the whole clip
+    assert torch.equal(st1, st)
+    d = torch.from_numpy(clip["depth"].copy())
+    rgb = torch.from_numpy(clip["rgb"]).float() / 255.0
+    for f in range(F):
+        ok = torch.from_numpy(O.reliable_depth_mask_range(clip["depth"][f]) & (clip["mask"][f] == 0))
+        d[f][~ok] = float("nan")
+        rgb[f][~ok] = float("nan")
+    t_d = torch.nan_to_num(torch.nanmean(d, dim=0), nan=0.0)
+    t_c = (torch.nan_to_num(torch.nanmean(rgb, dim=0), nan=0.0) * 255).clamp(0, 255).to(torch.uint8)
+    assert torch.equal(md.cpu(), t_d)
+    assert torch.equal(mc.cpu(), t_c)
+
+
+def test_render_frame_applies_the_entry_filters(engine):
+    """Clouds handed to egoprior_render_frame without a pass through egoprior_filter_cloud (per-frame dynamic points,
+    say) still obey the reference's entry filters: rows with a non-finite coordinate or a float32 norm >= 1e6 are never
+    drawn.  Same frame as filtering first, and as the oracle's."""
+    from egoprior import engine as eng
+    rng = np.random.default_rng(21)
+    n = 4000
+    pts = np.empty((n, 3), dtype=F32)
+    pts[:, 0] = rng.uniform(0.8, 2.0, n)  # a cluster well to the right of the image centre
+    pts[:, 1] = rng.uniform(-1.0, 1.0, n)
+    pts[:, 2] = rng.uniform(2.0, 3.0, n)
+    pts[5] = [0.0, 0.0, 1.0e6]          # norm == 1e6: dropped
+    pts[6] = [3.0e3, 0.0, 999999.0]     # norm just above: dropped
+    pts[7] = [5.0e2, 0.0, 9.99e5]       # norm below: drawn, next to the centre
+    pts[8] = [np.nan, 0.0, 3.0]
+    pts[9] = [0.0, np.inf, 3.0]
+    pts[10] = [0.0, 0.0, -np.inf]
+    pts[11] = [1e20, 1e20, 1e20]        # squares overflow to infinity
+    cols = rng.integers(2, 256, (n, 3), dtype=np.uint8)
+    He, We, ps = 64, 96, 4.0
+    Kc = np.array([[0.8 * We, 0, We / 2], [0, 0.8 * We, He / 2], [0, 0, 1]], dtype=F32)
+    T = np.eye(4, dtype=F32)
+    ref = O.render_points_pinhole(pts, cols, Kc, T, We, He, ps)
+    cam = eng.pinhole_camera(T[:3, :3], T[:3, 3], Kc, He, We)
+    rp = eng.make_raster_params(ps, He, We, K=20, rotate_cw=True, colors_gt1=-1)
+    good = engine.filter_cloud(pts, cols)
+    assert good.n() == n - 6
+    raw = engine.new_cloud(n)
+    rec = np.zeros((n, 4), dtype=F32)
+    rec[:, :3] = pts
+    c = cols.astype(np.uint32)
+    rec[:, 3] = (c[:, 0] | (c[:, 1] << 8) | (c[:, 2] << 16)).view(F32)
+    raw.points.copy_(torch.from_numpy(rec))
+    raw.count.fill_(n)
+    raw.flags.fill_(1)
+    img_good = engine.render_frame(cam, rp, good)["image"].cpu().numpy()
+    assert np.array_equal(img_good, ref)
+    assert np.array_equal(engine.render_frame(cam, rp, raw)["image"].cpu().numpy(), ref)
+    assert np.array_equal(engine.render_frame(cam, rp, good, raw)["image"].cpu().numpy(),
+                          O.render_points_pinhole(np.vstack([pts, pts]), np.vstack([cols, cols]), Kc, T, We, He, ps))
+    # the far point that passes the filter is really in the picture
+    assert ref[We // 2 - 3:We // 2 + 4, He // 2 - 4:He // 2 + 4].any()
+
+
 def test_bad_arguments_raise(engine):
     from egoprior import _lib, engine as eng
     rp = eng.make_raster_params(3.0, 32, 32)

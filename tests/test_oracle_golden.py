@@ -35,7 +35,7 @@ def test_nanmean_matches_torch_live():
     """Same check against torch itself (present on every box): shapes whose inner size is a multiple of 32 follow the
     cascade order the oracle restates."""
     rng = np.random.default_rng(7)
-    for shape, F in (((16, 32), 33), ((40, 56, 3), 21), ((8, 64), 300)):
+    for shape, F in (((16, 32), 33), ((40, 56, 3), 21), ((8, 64), 300), ((8, 32), 1000), ((4, 32), 4097)):
         x = rng.random((F,) + shape, dtype=np.float32)
         x[rng.random(x.shape) < 0.25] = np.nan
         ref = torch.nan_to_num(torch.nanmean(torch.from_numpy(x), dim=0), nan=0.0).numpy()

@@ -165,9 +165,27 @@ def test_white_pixel_mask_known_answers():
     f[1, 0] = [100, 0, 0]
     f[1, 1] = [0, 52, 0]   # 0.587 * 52 = 30.524
     f[1, 2] = [0, 0, 255]  # 0.114 * 255 = 29.07
-    logical, vis = O.white_pixel_mask(f, 30.0)
+    logical, vis = O.white_pixel_mask(f, 30.0, grey="float")
     assert logical.tolist() == [[1, 0, 1], [0, 1, 0]]
     assert vis.max() == 255 and vis.dtype == np.uint8
+    # PIL's integer luma rounds to nearest: [100, 0, 0] -> 29.9 -> 30 passes, [0, 0, 255] -> 29.07 -> 29 does not
+    logical, _ = O.white_pixel_mask(f, 30.0)
+    assert logical.tolist() == [[1, 0, 1], [1, 1, 0]]
+
+
+def test_pil_luma_matches_pil():
+    """The grey conversion the reference's post-processing script makes (PIL Image.convert("L")), against outputs of
+    PIL itself committed as a fixture, and against PIL live where it is installed."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "g4_pil_luma.npz")
+    assert np.array_equal(O.pil_luma(g["rgb"]), g["L"])
+    try:
+        from PIL import Image
+    except Exception:
+        return
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    assert np.array_equal(O.pil_luma(a), np.asarray(Image.fromarray(a, "RGB").convert("L")))
 
 
 def test_config_a_plumbing_on_the_cpu():

@@ -10,6 +10,8 @@
 
 #include <hip/hip_fp16.h>
 
+#include <mutex>
+
 namespace ep {
 
 // Depth maps come as float32 or, as the EXR files store them (vipe/utils/io.py:274-277), as float16; the conversion to
@@ -989,6 +991,63 @@ extern "C" int egoprior_unproject_frame_rays(const egoprior_unproject_params* p,
                                  d_count, d_flags, d_workspace, workspace_bytes, stream);
     return unproject_frame_t(p, reinterpret_cast<const float*>(d_depth), d_rays, d_rgb, d_mask, d_points, d_xyz64,
                              d_count, d_flags, d_workspace, workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------------------------
+// Scratch of egoprior_unproject_frame_noalloc: the selection flags (one byte per sample) and the per-1024 block counts
+// and offsets of the compaction.  A file-scope device array: every GPU the library runs on holds its own copy, at its
+// own address, until the process ends.  In host code the array's name is only a stand-in for HIP_SYMBOL(); the memory
+// is reached through the pointer hipGetSymbolAddress returns for the current device.
+#define EP_NOALLOC_SCRATCH_BYTES ((size_t)EGOPRIOR_NOALLOC_MAX_SAMPLES + 16 + 256 + 2 * (((size_t)EGOPRIOR_NOALLOC_MAX_SAMPLES / EP_CB + 2) * 4 + 256))
+static __device__ __align__(256) unsigned char scratch[EP_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device; written once under g_scratch_mu
+std::mutex g_scratch_mu;
+
+// Address of `scratch` on the current device (resolved on the first call on that device), or NULL with the error text set.
+void* scratch_on_current_device() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        ep_host::fail(EGOPRIOR_E_HIP, "hipGetDevice failed (or more than 64 devices)");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || ptr == nullptr) {
+            std::snprintf(ep_host::error_buffer(), 512, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace
+
+extern "C" int egoprior_unproject_frame_noalloc(const egoprior_unproject_params* p, const float* d_depth,
+                                                const uint8_t* d_rgb, const uint8_t* d_mask,
+                                                egoprior_point* d_points, double* d_xyz64, int32_t* d_count,
+                                                int32_t* d_flags, void* stream) {
+    if (p == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (p->H <= 0 || p->W <= 0 || p->subsample <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad frame geometry");
+    const int64_t Hs = (p->H + p->subsample - 1) / p->subsample, Ws = (p->W + p->subsample - 1) / p->subsample;
+    if (Hs * Ws > (int64_t)EGOPRIOR_NOALLOC_MAX_SAMPLES) {
+        std::snprintf(ep_host::error_buffer(), 512,
+                      "egoprior_unproject_frame_noalloc: %lld samples exceed the static scratch (at most %lld); use "
+                      "egoprior_unproject_frame with a caller-owned workspace",
+                      (long long)(Hs * Ws), (long long)EGOPRIOR_NOALLOC_MAX_SAMPLES);
+        return EGOPRIOR_E_UNSUPPORTED;
+    }
+    void* const ptr = scratch_on_current_device();
+    if (ptr == nullptr) return EGOPRIOR_E_HIP;
+    // Nothing in the scratch has to start at zero: the flags kernel writes every flag byte of this frame, the count
+    // kernel every block count, the scan (when it runs) every block offset, and nothing beyond this frame's extent is
+    // read -- so a call after a larger one is not disturbed by what that one left behind.
+    return unproject_frame_t(p, d_depth, (const float*)nullptr, d_rgb, d_mask, d_points, d_xyz64, d_count, d_flags,
+                             ptr, EP_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 extern "C" size_t egoprior_filter_workspace_bytes(int64_t N) { return N < 0 ? 0 : compact_ws_bytes(N > 0 ? N : 1); }

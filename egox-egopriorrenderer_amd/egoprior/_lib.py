@@ -13,6 +13,7 @@ CSRC = _PKG.parent / "csrc"
 LIB_PATH = CSRC / "libegoprior_hip.so"
 
 MAX_K = 20
+NOALLOC_MAX_SAMPLES = 8 * 1024 * 1024 + 256 * 1024
 TILE = 8
 
 E_OK, E_INVALID, E_WORKSPACE, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -59,6 +60,8 @@ SIGNATURES = {
                                            _vp]),
     "egoprior_unproject_frame_f16": (C.c_int, [C.POINTER(UnprojectParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                _sz, _vp]),
+    "egoprior_unproject_frame_noalloc": (C.c_int, [C.POINTER(UnprojectParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                   _vp]),
     "egoprior_unproject_frame_rays": (C.c_int, [C.POINTER(UnprojectParams), _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 _vp, _vp, _sz, _vp]),
     "egoprior_meanbg_state_bytes": (_sz, [_i32, _i32]),

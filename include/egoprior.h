@@ -119,6 +119,21 @@ int egoprior_unproject_frame_rays(const egoprior_unproject_params* p, const void
                                   egoprior_point* d_points, double* d_xyz64, int32_t* d_count, int32_t* d_flags,
                                   void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* egoprior_unproject_frame for callers that cannot allocate device memory or carry a workspace: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same inputs, outputs
+ * and results as egoprior_unproject_frame (float32 depth); the selection flags and block counters of the compaction
+ * live in a device array that is part of the library image (about 8.1 MiB per GPU the library runs on, held until the
+ * process ends) instead of a caller-owned workspace.  It calls no hipMalloc / hipFree or allocating routine.
+ * Limits: ceil(H/s) * ceil(W/s) <= EGOPRIOR_NOALLOC_MAX_SAMPLES (a 3840 x 2160 frame at subsample 1 fits), otherwise
+ * EGOPRIOR_E_UNSUPPORTED; every call on a GPU shares that GPU's array, so calls that overlap in time on one GPU
+ * (different streams, different threads) race -- serialise them, or use egoprior_unproject_frame with one workspace
+ * per stream.  The first call on each device resolves the array's address (hipGetSymbolAddress): make that call outside
+ * graph capture. */
+#define EGOPRIOR_NOALLOC_MAX_SAMPLES (8 * 1024 * 1024 + 256 * 1024)
+int egoprior_unproject_frame_noalloc(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
+                                     const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
+                                     int32_t* d_count, int32_t* d_flags, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Mean background  --  compute_robust_mean_tensors (:459-473) + the frame loop of build_mean_background_pointcloud
  * (:522-583) + colour quantisation (:638).

@@ -81,8 +81,7 @@ struct Opt {
 };
 Opt g_opts[] = {
     {"splat_variant", 0},  // 0: sweep, 512-record chunks; 1: register insertion only; 2: sweep, 64-record chunks;
-                           // 3: sweep, 1024-record chunks; 4: LDS broadcast reads in the sweep; 6: sampled bucket
-                           // boundaries; 10-16: stage timing probes (wrong output)
+                           // 3: sweep, 1024-record chunks; 4: sweep, 384-record chunks
     {"fill_pieces", 1},    // 1: fill pass without global atomics where possible (k_tile_fill_pieces), 0: always k_tile_fill
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
 };

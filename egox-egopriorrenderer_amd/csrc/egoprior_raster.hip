@@ -5,7 +5,7 @@
 //                     per-tile counts                                        [HBM-bound: 16 B in, 16 B out per point]
 //   k_tile_scan     : exclusive scan of the tile counts (one workgroup)
 //   k_tile_fill     : same rectangle, slots reserved per run of lanes, writes the tile-list entries (8 bytes: point
-//                     index and depth bits, for the default splat kernel; 16 bytes with NDC x, y for the others)
+//                     index and depth bits; the splat kernels fetch NDC x, y from the projected records)
 //   k_splat_sweep   : one wave per 8x8 tile, one lane per pixel; buckets the tile's points by key in LDS, sweeps them
 //                     front to back keeping each pixel's K smallest (depth-bits, index) keys, then composites and
 //                     writes the uint8 frame (and, on request, pytorch3d's idx / zbuf / dists)
@@ -113,8 +113,8 @@ __device__ __forceinline__ void count_point_global(bool live, int tx0, int tx1, 
 // The same run grouping straight on the global cursors (no LDS stage): one returning global atomic per run and tile.
 __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                                       uint32_t* __restrict__ cursor,
-                                                      const uint32_t* __restrict__ tile_start, uint4* __restrict__ list,
-                                                      uint32_t capacity, uint4 entry, int list8 = 0) {
+                                                      const uint32_t* __restrict__ tile_start, uint2* __restrict__ list,
+                                                      uint32_t capacity, uint2 entry) {
     const int lane = lane_id();
     const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
     if (!live) return;
@@ -125,12 +125,7 @@ __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx
             if (r.head) slot0 = tile_start[t] + atomicAdd(&cursor[t], r.len);
             // all lanes of a run walk the same rectangle, so the head is in this iteration too
             const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
-            if (slot < capacity) {
-                if (list8)  // index + depth bits only; the splat kernel fetches x, y from the NDC records
-                    reinterpret_cast<uint2*>(list)[slot] = make_uint2(entry.x, entry.y);
-                else
-                    list[slot] = entry;
-            }
+            if (slot < capacity) list[slot] = entry;
         }
     }
 }
@@ -191,7 +186,7 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
                     q.y = oy;
                     q.z = oz;
                     q.rgba = p.rgba;
-                    out[i] = q;
+                    if (out != nullptr) out[i] = q;  // NULL: counting only
                 } else {
                     ox = p.x;
                     oy = p.y;
@@ -309,12 +304,12 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
 
 // Second binning pass: writes the tile lists.  Every thread fetches its EP_BIN_PPT records together; the first lane of
 // a run (see lane_runs) reserves the run's slots in each tile of the rectangle with one returning global atomic and
-// hands them to its lanes, so the 16-byte entries of a run land in consecutive slots.
+// hands them to its lanes, so the entries of a run land in consecutive slots.
 __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_point* __restrict__ ndc, int64_t cap,
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
-                                                   uint32_t* __restrict__ tile_cursor, uint4* __restrict__ list,
-                                                   uint32_t capacity, int list8) {
+                                                   uint32_t* __restrict__ tile_cursor, uint2* __restrict__ list,
+                                                   uint32_t capacity) {
     const int64_t n = live_count(d_n, cap);
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
@@ -330,16 +325,15 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
             const int64_t i = base + k * 256 + threadIdx.x;
             int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
             const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
-            // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order), NDC x, y
+            // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order)
             const float oz = pin[k].z;
-            const uint4 entry = make_uint4((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz),
-                                           __float_as_uint(pin[k].x), __float_as_uint(pin[k].y));
-            bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry, list8);
+            const uint2 entry = make_uint2((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz));
+            bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
         }
     }
 }
 
-// The fill pass without global atomics, for 8-byte entries.  The counting pass added every workgroup's per-tile counts to
+// The fill pass without global atomics.  The counting pass added every workgroup's per-tile counts to
 // the global counters and kept what those atomics returned (wg_piece): that is where the workgroup's entries start
 // inside each tile's list.  The same grid over the same points runs here, so a workgroup only has to hand out the slots
 // inside its own pieces, which it does with returning LDS atomics on 16-bit cursors (two per word, as in the counting
@@ -410,7 +404,28 @@ typedef unsigned long long u64;
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
-__device__ uint32_t g_chunk_stats[16];
+// ... and the cycles all waves spent in each stage: load + filter, sort, sweep + append, merge, compositor
+__device__ unsigned long long g_stage_cycles[8];
+#define EP_STAGE(i_)                                                 \
+    {                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        stage_cyc[i_] += now_ - stage_t;                             \
+        stage_t = now_;                                              \
+    }
+#else
+#define EP_STAGE(i_)
+#endif
+// Diagnostic build only: STOP > 0 instantiations of the sweep kernel are instruction-count probes (option "splat_variant"
+// 11..14) whose chunk loop ends after the load (1), sort (2) or sweep (3) stage, or that skip the compositor (4); a
+// checksum keeps the skipped-over values alive.  They produce no image.
+#ifdef EP_TILE_TIMES
+#define EP_PROBE(n_, expr_)                                                                   \
+    if (STOP == n_) {                                                                         \
+        if ((uint32_t)(expr_) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;    \
+        continue;                                                                             \
+    }
+#else
+#define EP_PROBE(n_, expr_)
 #endif
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -420,6 +435,16 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ u64 make_key(uint32_t zbits, uint32_t idx) { return ((u64)zbits << 32) | (u64)idx; }
 
+// A value that is the same in every lane, moved to scalar registers (the compiler cannot see the uniformity of a
+// value that came out of a butterfly reduction or of float arithmetic on uniform operands).
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ u64 uniform_u64(u64 v) {
+    return ((u64)uniform_u32((uint32_t)(v >> 32)) << 32) | (u64)uniform_u32((uint32_t)v);
+}
+
 __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -428,7 +453,7 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
         const u64 o = ((u64)hi << 32) | lo;
         v = o > v ? o : v;
     }
-    return v;
+    return uniform_u64(v);
 }
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 #pragma unroll
@@ -438,25 +463,7 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
         const u64 o = ((u64)hi << 32) | lo;
         v = o < v ? o : v;
     }
-    return v;
-}
-
-// Sorts one 64-bit value per lane ascending across the wave (bitonic network over lane exchanges).
-__device__ __forceinline__ u64 wave_sort_u64(u64 v) {
-    const int lane = (int)threadIdx.x & 63;
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j);
-            const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j);
-            const u64 o = ((u64)hi << 32) | lo;
-            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-            const u64 mn = o < v ? o : v, mx = o < v ? v : o;
-            v = keep_min ? mn : mx;
-        }
-    }
-    return v;
+    return uniform_u64(v);
 }
 
 // Insert (nz, ni) into the per-lane list kept sorted ascending by key in registers (compare-exchange chain).
@@ -473,72 +480,97 @@ __device__ __forceinline__ void bubble_insert(uint32_t (&kz)[EP_K], uint32_t (&k
 }
 
 // Front-to-back compositing of a lane's sorted fragments + the reference's post-processing + optional fragment dump.
-// d2 is recomputed from the point's NDC x, y with the same operations as the hit test, so it is the same float.
-__device__ __forceinline__ void composite_and_store(const RasterGeom& g, const egoprior_raster_params& rp,
-                                                    const egoprior_point* __restrict__ ndc,
-                                                    const uint32_t (&kz)[EP_K], const uint32_t (&ki)[EP_K], int xi,
-                                                    int yi, float xf, float yf, const int32_t* __restrict__ d_flags_a,
-                                                    const int32_t* __restrict__ d_flags_b, const SplatOut& out) {
+// kz / ki: the pixel's fragments in ascending (z, index) order, "nothing" = all ones.  d2 is recomputed from the point's
+// NDC x, y with the same operations as the hit test, so it is the same float.
+// The winners' records are gathered GB at a time, all GB gathers in flight together: the gathers are random 16-byte
+// reads, and issued in small groups their round trips added up to nearly half of a splat wave's lifetime.  Groups of 5
+// whose slot no pixel of the wave fills are skipped (lists are filled front to back).
+// Colour bytes become floats through a 256-entry table in LDS (the byte divided by 255.0f, or the byte itself when the
+// cloud's colours are not to be scaled): a correctly rounded division costs ten instructions, and a pixel has sixty of
+// them.  Every lane of the wave fills four entries with that same division; `lut` must not be in use by anything else.
+__device__ __forceinline__ void fill_color_lut(float* lut, const egoprior_raster_params& rp,
+                                               const int32_t* __restrict__ d_flags_a,
+                                               const int32_t* __restrict__ d_flags_b, int lane) {
     int scale255 = rp.colors_gt1;
     if (scale255 < 0) {
         scale255 = 0;
         if (d_flags_a != nullptr && *d_flags_a != 0) scale255 = 1;
         if (d_flags_b != nullptr && *d_flags_b != 0) scale255 = 1;
     }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float b = (float)(lane * 4 + j);
+        lut[lane * 4 + j] = scale255 ? b / 255.0f : b;
+    }
+    __syncthreads();
+}
+
+template <int GB>
+__device__ __forceinline__ void composite_and_store(const RasterGeom& g, const egoprior_raster_params& rp,
+                                                    const egoprior_point* __restrict__ ndc,
+                                                    const uint32_t (&kz)[EP_K], const uint32_t (&ki)[EP_K], int xi,
+                                                    int yi, float xf, float yf, const float* lut, const SplatOut& out) {
     const int K = rp.K;
     const size_t pix = (size_t)yi * (size_t)g.W + (size_t)xi;
     float cum = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    constexpr int G = 5;  // fragments per gather group
-    static_assert(EP_K % G == 0, "group size");
+    constexpr int G = 5;  // fragments per skip group
+    static_assert(EP_K % GB == 0 && GB % G == 0, "batch and group sizes");
 #pragma unroll
-    for (int h = 0; h < EP_K; h += G) {
-        // lists are filled front to back: when no pixel of the wave has a fragment at slot h, none has one beyond
-        // (wave-uniform test: whole groups of gathers are skipped for sparsely covered tiles)
-        if (__ballot(h < K && ki[h] != 0xFFFFFFFFu) != 0ull) {
-            egoprior_point p[G];  // all gathers of the group are issued before any of them is used
+    for (int h0 = 0; h0 < EP_K; h0 += GB) {
+        egoprior_point p[GB];
+        bool any[GB / G];
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
-                p[k] = ndc[filled ? ki[h + k] : 0u];  // unconditional so that the gathers overlap
+        for (int gq = 0; gq < GB / G; ++gq) {
+            const int h = h0 + gq * G;
+            any[gq] = __ballot(h < K && ki[h] != 0xFFFFFFFFu) != 0ull;  // wave-uniform
+            if (any[gq]) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
+                    p[gq * G + k] = ndc[filled ? ki[h + k] : 0u];  // unconditional so that the gathers overlap
+                }
             }
+        }
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
-                float d2 = -1.0f;
-                if (filled) {
-                    const float dx = p[k].x - xf;
-                    const float dy = p[k].y - yf;
-                    d2 = dx * dx + dy * dy;
-                    float fr = (float)(p[k].rgba & 0xFFu), fg = (float)((p[k].rgba >> 8) & 0xFFu),
-                          fb = (float)((p[k].rgba >> 16) & 0xFFu);
-                    if (scale255) {
-                        fr = fr / 255.0f;
-                        fg = fg / 255.0f;
-                        fb = fb / 255.0f;
+        for (int gq = 0; gq < GB / G; ++gq) {
+            const int h = h0 + gq * G;
+            if (any[gq]) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const egoprior_point q = p[gq * G + k];
+                    const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
+                    float d2 = -1.0f;
+                    if (filled) {
+                        const float dx = q.x - xf;
+                        const float dy = q.y - yf;
+                        d2 = dx * dx + dy * dy;
+                        const float fr = lut[q.rgba & 0xFFu], fg = lut[(q.rgba >> 8) & 0xFFu],
+                                    fb = lut[(q.rgba >> 16) & 0xFFu];
+                        const float alpha = 1.0f - d2 / rp.radius_sq_w;
+                        const float wgt = cum * alpha;
+                        cr += wgt * fr;
+                        cg += wgt * fg;
+                        cb += wgt * fb;
+                        cum = cum * (1.0f - alpha);
                     }
-                    const float alpha = 1.0f - d2 / rp.radius_sq_w;
-                    const float wgt = cum * alpha;
-                    cr += wgt * fr;
-                    cg += wgt * fg;
-                    cb += wgt * fb;
-                    cum = cum * (1.0f - alpha);
+                    if (out.idx != nullptr && h + k < K) {
+                        const size_t o = pix * (size_t)K + (size_t)(h + k);
+                        out.idx[o] = filled ? (int32_t)ki[h + k] : -1;
+                        if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[h + k]) : -1.0f;
+                        if (out.dists != nullptr) out.dists[o] = d2;
+                    }
                 }
-                if (out.idx != nullptr && h + k < K) {
-                    const size_t o = pix * (size_t)K + (size_t)(h + k);
-                    out.idx[o] = filled ? (int32_t)ki[h + k] : -1;
-                    if (out.zbuf != nullptr) out.zbuf[o] = filled ? __uint_as_float(kz[h + k]) : -1.0f;
-                    if (out.dists != nullptr) out.dists[o] = d2;
-                }
-            }
-        } else if (out.idx != nullptr) {
+            } else if (out.idx != nullptr) {
 #pragma unroll
-            for (int k = 0; k < G; ++k)
-                if (h + k < K) {
-                    const size_t o = pix * (size_t)K + (size_t)(h + k);
-                    out.idx[o] = -1;
-                    if (out.zbuf != nullptr) out.zbuf[o] = -1.0f;
-                    if (out.dists != nullptr) out.dists[o] = -1.0f;
-                }
+                for (int k = 0; k < G; ++k)
+                    if (h + k < K) {
+                        const size_t o = pix * (size_t)K + (size_t)(h + k);
+                        out.idx[o] = -1;
+                        if (out.zbuf != nullptr) out.zbuf[o] = -1.0f;
+                        if (out.dists != nullptr) out.dists[o] = -1.0f;
+                    }
+            }
         }
     }
     if (out.image_f32 != nullptr) {
@@ -567,7 +599,7 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
                                                      const egoprior_point* __restrict__ ndc,
                                                      const uint32_t* __restrict__ tile_start,
                                                      const uint32_t* __restrict__ tile_order,
-                                                     const uint4* __restrict__ list, uint32_t capacity,
+                                                     const uint2* __restrict__ list, uint32_t capacity,
                                                      const int32_t* __restrict__ d_flags_a,
                                                      const int32_t* __restrict__ d_flags_b, SplatOut out) {
     __shared__ float4 recs[64];
@@ -593,9 +625,9 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
         const uint32_t nrec = min(64u, end - c0);
         __syncthreads();
         if ((uint32_t)lane < nrec) {
-            const uint4 e = list[c0 + lane];
-            recs[lane] = make_float4(__uint_as_float(e.z), __uint_as_float(e.w), __uint_as_float(e.y),
-                                     __uint_as_float(e.x));
+            const uint2 e = list[c0 + lane];  // point index, depth bits
+            const float2v xy = *reinterpret_cast<const float2v*>(&ndc[e.x].x);
+            recs[lane] = make_float4(xy.x, xy.y, __uint_as_float(e.y), __uint_as_float(e.x));
         }
         __syncthreads();
         for (uint32_t j = 0; j < nrec; ++j) {
@@ -609,57 +641,80 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
             if (take) bubble_insert(kz, ki, nz, ni);
         }
     }
+    fill_color_lut(reinterpret_cast<float*>(recs), rp, d_flags_a, d_flags_b, lane);
     if (!inside) return;
-    composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+    composite_and_store<10>(g, rp, ndc, kz, ki, xi, yi, xf, yf, reinterpret_cast<const float*>(recs), out);
 }
 
-// Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
-// entries (C/64 per lane, held in registers while the chunk is organised):
-//   load    : C/64 independent, fully coalesced 16-byte record loads per lane (the tile lists hold index, depth
-//             bits and NDC x, y); records whose key cannot beat the largest K-th key of the tile's pixels (T) are
-//             dropped, which removes about half of every chunk after the first
-//   sort    : a monotone two-level bucket map sends the keys to LDS in O(n).  Level 1 cuts the chunk's key range
-//             into NB equal ranges and histograms them; a range holding c records is cut again into 2^floor(log2 c)
-//             sub-ranges, so buckets hold a record or two unless depths repeat.  (SAMPLED builds take 64 sorted
-//             sample keys as level-1 splitters instead.)  After the scatter every record ranks itself inside its
-//             bucket: short buckets by reading their neighbours' keys, medium ones (up to EP_RANK_WAVE) with a
-//             wave-wide all-pairs count, and a chunk with a longer bucket is bitonic-sorted.  S[] ends up sorted.
-//   sweep   : the sorted records are offered front to back, 64 at a time, to the 64 pixels.  With many open pixels
-//             each lane walks the 64 records (LDS broadcast reads) and shifts one hit bit per record into its
-//             mask; with few open pixels the roles swap: each lane holds one record, the open pixels' coordinates
-//             come from v_readlane and a ballot is the pixel's mask.  Hits are appended to the pixel's slot list two
-//             per trip.  Sorted input makes the first K hits of a pixel its K nearest, so a pixel closes at K hits
-//             (and, from the second chunk on, at the first record beyond its own K-th key).
-//   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
-//             later chunks: a fixed bitonic merge network over the two sorted lists).
-// LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space).
-// DBG != 0 builds are timing probes only (option "splat_variant" 10..13): the chunk loop stops after the load (1),
-// the sort (2) or the sweep (3) stage and nothing is composited; a checksum keeps the skipped-over values alive.
 // Value of lane K of the caller's row of 16 lanes.  The compiler folds the move into the instruction that uses it.
 template <int K>
 __device__ __forceinline__ float row_bcast(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + K, 0xf, 0xf, true));
 }
 
-template <int C, int NB, int WPE, int DBG = 0, int PIXMAJ = 24, bool SAMPLED = false, bool ROWBCAST = true, bool LIST8 = false>
+// Compare-exchange of two entries of a pixel's running list: the larger key goes to position a.  (Keys are held as
+// 64-bit values throughout, so that each one lives in an aligned register pair and the compares need no re-pairing;
+// both values are copied to locals first: with an array element as an arm of ?: the compiler emits a branch.)
+__device__ __forceinline__ void ce_desc(u64 (&kl)[EP_K], int a, int b) {
+    const u64 ka = kl[a], kb = kl[b];
+    const bool sw = kb > ka;
+    kl[a] = sw ? kb : ka;
+    kl[b] = sw ? ka : kb;
+}
+
+__device__ __forceinline__ u64 lds_key(const uint4* rec) { return *reinterpret_cast<const u64*>(rec); }
+
+constexpr int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
+// entries (C/64 per lane, held in registers while the chunk is organised):
+//   load    : C/64 independent, fully coalesced 8-byte entry loads per lane (point index and depth bits); entries whose
+//             key cannot beat the largest K-th key of the tile's pixels (T) are dropped, the NDC x, y of the others are
+//             gathered from the point records, and discs that overlap the tile's rectangle without reaching any of its
+//             pixel centres are dropped too
+//   sort    : a monotone two-level bucket map sends the keys to LDS in O(n).  Level 1 cuts the chunk's key range
+//             into NB equal ranges and histograms them; a range holding c records is cut again into 2^floor(log2 c)
+//             sub-ranges, so buckets hold a record or two unless depths repeat.  After the scatter every record ranks
+//             itself inside its bucket: short buckets by reading their neighbours' keys, medium ones (up to
+//             EP_RANK_WAVE) with a wave-wide all-pairs count, and a chunk with a longer bucket is bitonic-sorted.
+//             S[] ends up sorted.
+//   sweep   : the sorted records are offered front to back, 64 at a time, to the 64 pixels.  With many open pixels
+//             sixteen records at a time sit one per lane in every row of 16 lanes and reach the row's pixels as DPP row
+//             broadcasts, one hit bit per record is shifted into the pixel's mask; with few open pixels the roles swap:
+//             each lane holds one record, the open pixels' coordinates come from v_readlane and a ballot is the
+//             pixel's mask.  Hits are appended to the pixel's slot list two per trip.  Sorted input makes the first K
+//             hits of a pixel its K nearest, so a pixel closes at K hits (and, from the second chunk on, at the first
+//             record beyond its own K-th key).
+//   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
+//             later chunks: a 40-exchange bitonic merge network that works in place on the running list).
+// The running list is kept in DESCENDING key order: position p holds the pixel's (EP_K-1-p)-th nearest fragment, empty
+// positions (all ones) come first.  With the chunk's winners B in ascending order, min(list[p], B[p]) for every p is
+// then the EP_K smallest keys of both as a rising-then-falling sequence, which the network sorts back to descending
+// order without any scratch registers.
+// LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space): 8.6 KiB
+// for C = 384, so that four waves per SIMD (16 per CU) fit the 160 KiB of a CU.
+template <int C, int NB, int WPE, int PIXMAJ = 24, int STOP = 0>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ tile_order,
-                                                    const uint4* __restrict__ list, uint32_t capacity,
+                                                    const uint2* __restrict__ list, uint32_t capacity,
                                                     const int32_t* __restrict__ d_flags_a,
                                                     const int32_t* __restrict__ d_flags_b, SplatOut out) {
-    static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 32768 && (C & (C - 1)) == 0 && (NB & (NB - 1)) == 0, "geometry");
+    static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 1024 && (NB & (NB - 1)) == 0 && NB >= C, "geometry");
     constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
     constexpr int PER = NB / 64;  // buckets per lane
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
     // The bucket counters are dead once a chunk is sorted and the slot lists are dead once it is merged, so the two share
-    // storage: with C = NB = 1024 a wave needs exactly 20 KiB and eight waves fit a CU's 160 KiB.
+    // storage.
     constexpr int AUXB = (NB * 4 > (EP_K + 1) * 64 * 2) ? NB * 4 : (EP_K + 1) * 64 * 2;  // K slot rows + a spare one
     __shared__ __align__(16) unsigned char aux[AUXB];
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
     uint16_t(*const slots)[64] = reinterpret_cast<uint16_t(*)[64]>(aux);
-    static_assert(NB >= C, "the two-level bucket map uses up to C buckets");
 
     const int tile = (int)tile_order[blockIdx.x];
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
@@ -671,25 +726,19 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     const float yf = pix_to_ndc(g.H - 1 - yi, g.H, g.W);
     const float r2 = g.radius2;
     const int K = rp.K;
-    float2v pxy;
-    pxy.x = xf;
-    pxy.y = yf;
     // The binning works on tile rectangles, so a list also holds discs that overlap the rectangle's corner tile without
     // reaching any of its pixel centres.  They are dropped at load time: [cx_lo, cx_hi] x [cy_lo, cy_hi] is the box of the
     // tile's pixel centres, a disc whose centre is farther than r from it cannot hit (the margin on r^2 is far above the
     // rounding of either evaluation, so nothing that the exact test would accept is dropped).
-    const float cx_hi = pix_to_ndc(g.W - 1 - txi * EP_TILE, g.W, g.H);
-    const float cx_lo = pix_to_ndc(g.W - 1 - (txi * EP_TILE + EP_TILE - 1), g.W, g.H);
-    const float cy_hi = pix_to_ndc(g.H - 1 - tyi * EP_TILE, g.H, g.W);
-    const float cy_lo = pix_to_ndc(g.H - 1 - (tyi * EP_TILE + EP_TILE - 1), g.H, g.W);
-    const float r2_reach = r2 * 1.0001f;
+    const float cx_hi = uniform_f32(pix_to_ndc(g.W - 1 - txi * EP_TILE, g.W, g.H));
+    const float cx_lo = uniform_f32(pix_to_ndc(g.W - 1 - (txi * EP_TILE + EP_TILE - 1), g.W, g.H));
+    const float cy_hi = uniform_f32(pix_to_ndc(g.H - 1 - tyi * EP_TILE, g.H, g.W));
+    const float cy_lo = uniform_f32(pix_to_ndc(g.H - 1 - (tyi * EP_TILE + EP_TILE - 1), g.H, g.W));
+    const float r2_reach = uniform_f32(r2 * 1.0001f);
 
-    uint32_t kz[EP_K], ki[EP_K];
+    u64 kl[EP_K];  // (depth bits << 32 | index), descending: position EP_K-1-a holds the a-th nearest fragment
 #pragma unroll
-    for (int k = 0; k < EP_K; ++k) {
-        kz[k] = 0xFFFFFFFFu;
-        ki[k] = 0xFFFFFFFFu;
-    }
+    for (int k = 0; k < EP_K; ++k) kl[k] = ~0ull;
     u64 T = ~0ull;  // only keys below T can still enter some pixel's top K
     uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
     if (end > capacity) end = capacity;
@@ -698,140 +747,55 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #ifdef EP_TILE_TIMES
     const unsigned long long tt0 = __builtin_readcyclecounter();
     const uint32_t tt_records = end - pos;
+    unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
 #endif
 
     while (pos < end) {
         // ---- load + threshold filter -----------------------------------------------------------------------------
-        uint4 rec[RPL];
+        u64 key[RPL];               // depth bits << 32 | point index
+        uint32_t rx[RPL], ry[RPL];  // NDC x, y bits
         bool val[RPL];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
             const uint32_t e = pos + (uint32_t)(u * 64 + lane);
             val[u] = e < end;
-            if (LIST8) {
-                const uint2 e2 = reinterpret_cast<const uint2*>(list)[val[u] ? e : end - 1u];
-                rec[u] = make_uint4(e2.x, e2.y, 0u, 0u);
-            } else {
-                rec[u] = list[val[u] ? e : end - 1u];  // unconditional (clamped) so that all loads are in flight together
-            }
+            // unconditional (clamped): all loads are in flight together; an entry is (index, depth bits) = the key as it is
+            key[u] = reinterpret_cast<const u64*>(list)[val[u] ? e : end - 1u];
         }
-        if (LIST8) {
-            // second round trip: x, y of the entries that pass the threshold (the others read record 0)
+        // second round trip: x, y of the entries that pass the threshold (the others read record 0)
 #pragma unroll
-            for (int u = 0; u < RPL; ++u) {
-                const bool want = val[u] && (make_key(rec[u].y, rec[u].x) < T);
-                const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? rec[u].x : 0u].x);
-                rec[u].z = __float_as_uint(xy.x);
-                rec[u].w = __float_as_uint(xy.y);
-            }
+        for (int u = 0; u < RPL; ++u) {
+            const bool want = val[u] && (key[u] < T);
+            const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? (uint32_t)key[u] : 0u].x);
+            rx[u] = __float_as_uint(xy.x);
+            ry[u] = __float_as_uint(xy.y);
         }
         u64 kmin = ~0ull, kmax = 0ull;
         int m = 0;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            const u64 key = make_key(rec[u].y, rec[u].x);
-            const float px = __uint_as_float(rec[u].z), py = __uint_as_float(rec[u].w);
+            const float px = __uint_as_float(rx[u]), py = __uint_as_float(ry[u]);
             const float ox = fmaxf(fmaxf(cx_lo - px, px - cx_hi), 0.0f), oy = fmaxf(fmaxf(cy_lo - py, py - cy_hi), 0.0f);
-            val[u] = val[u] && (key < T) && !(ox * ox + oy * oy > r2_reach);
-            if (val[u]) {
-                kmin = key < kmin ? key : kmin;
-                kmax = key > kmax ? key : kmax;
-            }
+            val[u] = val[u] && (key[u] < T) && !(ox * ox + oy * oy > r2_reach);
+            const u64 klo = val[u] ? key[u] : ~0ull, khi = val[u] ? key[u] : 0ull;
+            kmin = klo < kmin ? klo : kmin;
+            kmax = khi > kmax ? khi : kmax;
             m += __popcll(__ballot(val[u]));
         }
         pos += C;
-        if (DBG == 1) {
-            uint32_t cs = 0;
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) cs += rec[u].x ^ rec[u].y ^ rec[u].z ^ rec[u].w;
-            if (cs == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
-            continue;
-        }
-#ifdef EP_CHUNK_STATS
-        if (lane == 0) {
-            atomicAdd(&g_chunk_stats[0], 1u);                          // chunks loaded
-            atomicAdd(&g_chunk_stats[1], (uint32_t)(chunk_no > 0));    // ... after the first
-            atomicAdd(&g_chunk_stats[2], (uint32_t)(chunk_no > 0 && T == ~0ull));  // ... of those, unfiltered
-            atomicAdd(&g_chunk_stats[3], (uint32_t)m);                 // records kept
-            atomicAdd(&g_chunk_stats[4], (uint32_t)(chunk_no > 0 ? m : 0));
-            atomicAdd(&g_chunk_stats[5], (uint32_t)((chunk_no > 0 && T == ~0ull) ? m : 0));
-        }
-#endif
+        EP_STAGE(0)
+        EP_PROBE(1, (uint32_t)key[0] ^ rx[0] ^ ry[RPL - 1] ^ (uint32_t)m)
         if (m == 0) continue;
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
-        // Two-level monotone bucket map: 64 level-1 ranges, one per lane; range c, which received cc records, is cut
-        // into 2^floor(log2 cc) equal sub-ranges, so buckets hold a record or two wherever the keys are locally uniform,
-        // however unevenly the ranges are populated.
+        // Two-level monotone bucket map.  Level 1: NB equal-width ranges of [kmin, kmax].  Their histogram, and then the
+        // table that maps a range to its first bucket and sub-range count, live in the first bytes of S, which is not in
+        // use until the scatter.  Range c, which received cc records, is cut into 2^floor(log2 cc) equal sub-ranges, so
+        // buckets hold a record or two wherever the keys are locally uniform, however unevenly the ranges are populated.
         uint32_t bq[RPL];
-        if (SAMPLED) {
-            // Level-1 boundaries are a sorted sample of the chunk's own keys (one per lane, taken across the whole
-            // chunk): every range then holds about the same number of records whatever the depths look like.
-            u64 sk = ~0ull;
-#pragma unroll
-            for (int u = 0; u < RPL; ++u)
-                if (val[u] && (lane & (RPL - 1)) == u) sk = make_key(rec[u].y, rec[u].x);
-            sk = wave_sort_u64(sk);
-            __syncthreads();  // previous chunk's readers of S / bkt / slots are done
-            // S is not in use until the scatter: its first bytes hold the range table meanwhile
-            u64* const spl = reinterpret_cast<u64*>(S);                  // [64] lower bound of range c
-            uint2* const rinf = reinterpret_cast<uint2*>(S) + 64;  // [64] first bucket | last sub-range << 16, scale
-            const u64 rlo = (lane == 0) ? kmin : sk;
-            spl[lane] = rlo;
-            bkt[lane] = 0u;  // the first 64 counters take the level-1 histogram, then all are cleared for level 2
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) {
-                // range = number of boundaries 1..63 that are <= key (records that were filtered out look up key 0)
-                const u64 key = val[u] ? make_key(rec[u].y, rec[u].x) : 0ull;
-                uint32_t r = 0;
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (spl[r + step] <= key) r += step;
-                bq[u] = r;
-            }
-#pragma unroll
-            for (int u = 0; u < RPL; ++u)
-                if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
-            __syncthreads();
-            {
-                const uint32_t cc = bkt[lane];
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < PER; ++q) bkt[q * 64 + lane] = 0u;
-                const uint32_t nlo = (uint32_t)__shfl_down((int)(uint32_t)sk, 1);
-                const uint32_t nhi = (uint32_t)__shfl_down((int)(uint32_t)(sk >> 32), 1);
-                u64 rhi = ((u64)nhi << 32) | nlo;                  // next range's lower bound ...
-                if (lane == 63 || rhi > kmax) rhi = kmax + 1ull;  // ... or the end of the key range
-                const u64 w = (rhi > rlo) ? rhi - rlo : 1ull;
-                const int fl = (cc <= 1u) ? 0 : (31 - __builtin_clz(cc));  // floor(log2 cc)
-                const uint32_t nf = (cc == 0u) ? 0u : (1u << fl);
-                uint32_t incl = nf;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(incl, d);
-                    if (lane >= d) incl += o;
-                }
-                // sub-range of a key = floor((key - lower bound) * nf / w), evaluated in float32: rounding may merge or
-                // shift neighbours but keeps the map monotone, which is all the sort needs
-                rinf[lane] = make_uint2((incl - nf) | ((nf == 0u ? 0u : nf - 1u) << 16),
-                                        __float_as_uint((float)nf / (float)w));
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < RPL; ++u) {
-                const uint32_t r = bq[u];
-                const u64 lo = spl[r];
-                const uint2 info = rinf[r];
-                const u64 d = make_key(rec[u].y, rec[u].x) - lo;
-                const uint32_t sub = min((uint32_t)((float)d * __uint_as_float(info.y)), info.x >> 16);
-                bq[u] = val[u] ? (info.x & 0xFFFFu) + sub : 0u;
-            }
-        } else {
-            // Level 1: NB equal-width ranges of [kmin, kmax].  Their histogram, and then the table that maps a range to
-            // its first bucket and sub-range count, live in the first bytes of S, which is not in use until the scatter.
+        {
             constexpr int LOGR = __builtin_ctz((unsigned)NB);
-            static_assert(8 * NB <= 16 * C, "the level-1 table fits into S");
+            static_assert(4 * NB <= 16 * C, "the level-1 table fits into S");
             const u64 range = kmax - kmin;
             int cshift = 0;
             if (range >= (u64)NB) cshift = (64 - __builtin_clzll(range)) - LOGR;
@@ -845,7 +809,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
-                if (val[u]) atomicAdd(&h1[(uint32_t)((make_key(rec[u].y, rec[u].x) - kmin) >> cshift)], 1u);
+                if (val[u]) atomicAdd(&h1[(uint32_t)((key[u] - kmin) >> cshift)], 1u);
             __syncthreads();
             {
                 uint32_t inf[PER];  // sub-ranges | log2(sub-ranges) << 16 of this lane's PER ranges
@@ -875,7 +839,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
-                const u64 d = val[u] ? make_key(rec[u].y, rec[u].x) - kmin : 0ull;  // filtered-out records: range 0
+                const u64 d = val[u] ? key[u] - kmin : 0ull;  // filtered-out records: range 0
                 const uint32_t c = (uint32_t)(d >> cshift);
                 const uint32_t info = h1[c];
                 const int fl = (int)(info >> 16);
@@ -912,78 +876,66 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
         }
         __syncthreads();
-        // From here on only the key half of a record stays in registers; sp[u] remembers where the record went.
-        uint32_t kx[RPL], ky[RPL], sp[RPL];
+        // From here on only the key half of a record stays in registers; the scatter position goes into posf[u].
+        // posf[u] = bucket start | scatter position << 10 | bucket length << 20, sign bit = nothing to place
+        static_assert(C <= 1024, "positions are packed into 10 bits");
+        int posf[RPL];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            kx[u] = rec[u].x;
-            ky[u] = rec[u].y;
-            sp[u] = 0u;
+            posf[u] = 0;
             if (val[u]) {
-                sp[u] = atomicAdd(&bkt[bq[u]], 1u);
-                S[sp[u]] = rec[u];
+                const uint32_t sp = atomicAdd(&bkt[bq[u]], 1u);
+                S[sp] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), rx[u], ry[u]);
+                posf[u] = (int)(sp << 10);
             }
         }
         __syncthreads();
         // the sweep reads whole blocks of 64: pad the last block with records that never hit and sort last
         for (int i = m + lane; i < ((m + 63) & ~63); i += 64)
             S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
-        if (DBG == 5) {
-            const uint4 q = S[lane];
-            if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
-            continue;
-        }
         // bkt[b] is now the end of bucket b and S holds the records in bucket order.  Order inside a bucket:
         //  - up to EP_RANK_SELF records: every record (still in this lane's registers) counts the keys of its own bucket
         //    that are smaller than its key; keys are unique, so start + count is its final position;
         //  - up to EP_RANK_WAVE records: the wave ranks the bucket together afterwards (all pairs: each lane holds up to
         //    two of its records and every key of the bucket is read once, as a broadcast);
         //  - anything longer (a long run of equal depths): bitonic sort of the whole chunk.
-        // posf[u] = bucket start | scatter position << 10 | bucket length << 20, sign bit = nothing to place
-        static_assert(C <= 1024, "positions are packed into 10 bits");
-        int posf[RPL];
         int big = 0;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            posf[u] = (int)0x80100000u;
             if (val[u]) {
                 const int bs = (bq[u] == 0u) ? 0 : (int)bkt[bq[u] - 1u];
                 const int be = (int)bkt[bq[u]];
-                posf[u] = bs | (int)(sp[u] << 10) | ((be - bs) << 20);
+                posf[u] |= bs | ((be - bs) << 20);
                 big = max(big, be - bs);
+            } else {
+                posf[u] = (int)0x80100000u;
             }
         }
-        if (DBG == 6) {
-            // timing probe: leave the records in bucket order (wrong output, same downstream work)
-        } else if (__ballot(big > (DBG == 7 ? 4096 : EP_RANK_WAVE)) == 0ull) {
-            // The first 4 keys of the bucket are fetched unconditionally (clamped), 4 records at a time, so that 16
+        if (__ballot(big > EP_RANK_WAVE) == 0ull) {
+            // The first 4 keys of the bucket are fetched unconditionally (clamped), two records at a time, so that 8
             // independent LDS reads are in flight together; only buckets with more than 4 records loop.
 #pragma unroll
-            for (int u0 = 0; u0 < RPL; u0 += 4) {
-                uint2 kk[4][4];
+            for (int u0 = 0; u0 < RPL; u0 += 2) {
+                u64 kk[2][4];
 #pragma unroll
-                for (int a4 = 0; a4 < 4; ++a4) {
-                    const int u = u0 + a4;
+                for (int a2 = 0; a2 < 2; ++a2) {
+                    const int u = (u0 + a2 < RPL) ? u0 + a2 : u0;
                     const int bs = posf[u] & 1023, bsz = (posf[u] >> 20) & 2047;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        kk[a4][j] = *reinterpret_cast<const uint2*>(&S[bs + min(j, bsz - 1)]);
+                        kk[a2][j] = lds_key(&S[bs + min(j, bsz - 1)]);
                 }
 #pragma unroll
-                for (int a4 = 0; a4 < 4; ++a4) {
-                    const int u = u0 + a4;
+                for (int a2 = 0; a2 < 2; ++a2) {
+                    if (u0 + a2 >= RPL) continue;
+                    const int u = u0 + a2;
                     const int bs = posf[u] & 1023, bsz = (posf[u] >> 20) & 2047;
                     int fin = -1;  // negative: nothing to place, or left to the wave-wide pass below
                     if (posf[u] >= 0 && bsz <= EP_RANK_SELF) {
-                        const u64 key = make_key(ky[u], kx[u]);
                         int r = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            r += (j < bsz && make_key(kk[a4][j].y, kk[a4][j].x) < key) ? 1 : 0;
-                        for (int j = 4; j < bsz; ++j) {
-                            const uint2 k2 = *reinterpret_cast<const uint2*>(&S[bs + j]);
-                            r += (make_key(k2.y, k2.x) < key) ? 1 : 0;
-                        }
+                        for (int j = 0; j < 4; ++j) r += (j < bsz && kk[a2][j] < key[u]) ? 1 : 0;
+                        for (int j = 4; j < bsz; ++j) r += (lds_key(&S[bs + j]) < key[u]) ? 1 : 0;
                         fin = bs + r;
                     }
                     posf[u] = (fin < 0) ? -1 : (fin | (posf[u] & (1023 << 10)));
@@ -996,7 +948,8 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < RPL; ++u)
-                if (posf[u] >= 0) S[posf[u] & 1023] = make_uint4(kx[u], ky[u], zw[u].x, zw[u].y);
+                if (posf[u] >= 0)
+                    S[posf[u] & 1023] = make_uint4((uint32_t)key[u], (uint32_t)(key[u] >> 32), zw[u].x, zw[u].y);
             // wave-wide pass over the long buckets, one after the other (lane L owns buckets L*PER .. L*PER+PER-1)
             u64 has = __ballot(bigmask != 0u);
             while (has != 0ull) {
@@ -1017,8 +970,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                         rank[r] = 0;
                     }
                     for (int i = 0; i < n; ++i) {
-                        const uint2 k2 = *reinterpret_cast<const uint2*>(&S[bs + i]);
-                        const u64 ko = make_key(k2.y, k2.x);
+                        const u64 ko = lds_key(&S[bs + i]);
 #pragma unroll
                         for (int r = 0; r < EP_RANK_WAVE / 64; ++r) rank[r] += (ko < make_key(mine[r].y, mine[r].x)) ? 1 : 0;
                     }
@@ -1029,20 +981,30 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 }
             }
         } else {
-            // degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk
+            // Degenerate key distribution (long runs of equal depth): bitonic sort of the whole chunk, written with
+            // ascending compare-exchanges only (each merge starts with a flip stage), so that the positions from C up to
+            // the next power of two can stay virtual: they would hold "nothing" records, which never move.
+            constexpr int P2 = next_pow2(C);
             for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
             __syncthreads();
-            for (int k2 = 2; k2 <= C; k2 <<= 1) {
+            for (int k2 = 2; k2 <= P2; k2 <<= 1) {
                 for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-                    for (int t = lane; t < C / 2; t += 64) {
-                        const int lo = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
-                        const int hi = lo | j2;
-                        const bool up = (lo & k2) == 0;
-                        const uint4 ra = S[lo], rb = S[hi];
-                        const bool gt = make_key(ra.y, ra.x) > make_key(rb.y, rb.x);
-                        if (gt == up) {
-                            S[lo] = rb;
-                            S[hi] = ra;
+                    for (int t = lane; t < P2 / 2; t += 64) {
+                        int lo, hi;
+                        if (j2 == (k2 >> 1)) {  // flip: position i of a block of k2 against position k2-1-i
+                            const int blk = t / j2, i = t - blk * j2;
+                            lo = blk * k2 + i;
+                            hi = blk * k2 + k2 - 1 - i;
+                        } else {
+                            lo = ((t & ~(j2 - 1)) << 1) | (t & (j2 - 1));
+                            hi = lo | j2;
+                        }
+                        if (hi < C) {
+                            const uint4 ra = S[lo], rb = S[hi];
+                            if (make_key(ra.y, ra.x) > make_key(rb.y, rb.x)) {
+                                S[lo] = rb;
+                                S[hi] = ra;
+                            }
                         }
                     }
                     __syncthreads();
@@ -1050,12 +1012,9 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
         }
         __syncthreads();
+        EP_STAGE(1)
+        EP_PROBE(2, S[lane].x ^ S[lane].w)
 
-        if (DBG == 2) {
-            const uint4 q = S[lane];
-            if ((q.x ^ q.y) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
-            continue;
-        }
         // ---- sweep front to back ---------------------------------------------------------------------------------
         int cnt = inside ? 0 : K;  // pixels outside the image never take part
         // Later chunks: a pixel whose running list is full only cares about records with a key below its K-th key,
@@ -1064,14 +1023,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         if (chunk_no > 0) {
             u64 mine = ~0ull;
 #pragma unroll
-            for (int k = 0; k < EP_K; ++k)
-                if (k == K - 1) mine = make_key(kz[k], ki[k]);
+            for (int p = 0; p < EP_K; ++p)
+                if (p == EP_K - K) mine = kl[p];
             int lo = 0, hi = m;  // first position whose key is >= mine
             while (__ballot(lo < hi) != 0ull) {
                 if (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    const uint4 r = S[mid];
-                    if (make_key(r.y, r.x) < mine)
+                    if (lds_key(&S[mid]) < mine)
                         lo = mid + 1;
                     else
                         hi = mid;
@@ -1082,20 +1040,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         int m_sweep = jlim;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
+        m_sweep = (int)uniform_u32((uint32_t)m_sweep);
         for (int j0 = 0; j0 < m_sweep; j0 += 64) {
             const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
             if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
-            // Offer records j0 .. j0+63 to every pixel: each record's (x, y) is read from LDS at a wave-uniform
-            // address (a broadcast), subtracted and squared as a float pair, and the hit bit is shifted into the
-            // pixel's mask.  Slots past m hold infinite coordinates (written by the sort stage), which never hit.
+            // Offer records j0 .. j0+63 to every pixel.  Slots past m hold infinite coordinates (written by the sort
+            // stage), which never hit.
             uint32_t hm_lo = 0u, hm_hi = 0u;
-#ifdef EP_CHUNK_STATS
-            if (lane == 0) {
-                const bool rm = PIXMAJ && __popcll(act) <= PIXMAJ;
-                atomicAdd(&g_chunk_stats[(rm ? 8 : 6) + (chunk_no > 0 ? 1 : 0)], rm ? (uint32_t)__popcll(act) : 1u);
-                atomicAdd(&g_chunk_stats[10 + (chunk_no > 0 ? 1 : 0)], (uint32_t)__popcll(act));  // open pixels offered
-            }
-#endif
             if (PIXMAJ && __popcll(act) <= PIXMAJ) {
                 // Few pixels are still open: turn the test around.  Every lane holds one record of the block and the
                 // open pixels are visited one by one (their coordinates travel through scalar registers); the
@@ -1115,10 +1066,12 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     hm_lo = (lane == p) ? (uint32_t)hit : hm_lo;
                     hm_hi = (lane == p) ? (uint32_t)(hit >> 32) : hm_hi;
                 }
-            } else if (ROWBCAST) {
+            } else {
                 // Sixteen records at a time sit one per lane in every row of 16 lanes; a record's coordinates reach the
                 // other lanes of the row as the broadcast operand of the subtraction itself (DPP row broadcast), so the
-                // inner loop reads no LDS at all.  Two records share each packed multiply / add / subtract of r2.
+                // inner loop reads no LDS at all.  Two records share each packed multiply / add / subtract of r2.  d2 < r2
+                // exactly when d2 - r2 is negative (the difference of two floats is zero only if they are equal; record
+                // coordinates are never NaN with the sign bit set): its sign bit is shifted into the mask.
 #pragma unroll
                 for (int h = 1; h >= 0; --h) {  // records go in last to first, 32 per mask word
                     uint32_t bits = 0u;
@@ -1147,29 +1100,6 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     else
                         hm_hi = bits;
                 }
-            } else
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {  // 16 records per group: all LDS reads first, then the arithmetic
-                float2v rxy[16];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) rxy[t] = *reinterpret_cast<const float2v*>(&S[j0 + g4 * 16 + t].z);
-                __builtin_amdgcn_sched_barrier(0);
-                // d2 < r2 exactly when d2 - r2 is negative (the difference of two floats is zero only if they are equal;
-                // record coordinates are never NaN with the sign bit set): its sign bit is shifted into the mask.  The
-                // records go in last to first, so record t of the group ends up in bit t.
-                uint32_t bits = 0u;
-#pragma unroll
-                for (int t = 15; t >= 0; --t) {
-                    const float2v dxy = rxy[t] - pxy;
-                    const float2v q = dxy * dxy;
-                    const float d2 = q.x + q.y;
-                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d2 - r2), 31);
-                }
-                if (g4 < 2)
-                    hm_lo |= bits << (16 * g4);
-                else
-                    hm_hi |= bits << (16 * (g4 - 2));
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (cnt >= K || j0 >= jlim) {
                 hm_lo = 0u;
@@ -1205,68 +1135,44 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
         }
         __syncthreads();
+        EP_STAGE(2)
+        EP_PROBE(3, (uint32_t)cnt + slots[0][lane])
 
-        if (DBG == 3) {
-            if ((uint32_t)(cnt + slots[0][lane]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
-            continue;
-        }
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
         const int won = inside ? cnt : 0;
         if (chunk_no == 0) {
 #pragma unroll
             for (int k = 0; k < EP_K; ++k) {
-                if (k < won) {
-                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[k][lane]]);
-                    kz[k] = w.y;
-                    ki[k] = w.x;
-                }
+                if (k < won) kl[EP_K - 1 - k] = lds_key(&S[slots[k][lane]]);
             }
         } else if (__ballot(won > 0) != 0ull) {
-            // Both lists are sorted: merge them with a fixed compare-exchange network.  Padded to 32 entries with
-            // "nothing" keys, L[i] = min(A[i], B[31 - i]) holds the 32 smallest of both lists as a bitonic sequence; five
-            // half-cleaner stages sort it and its first EP_K entries are the new running list.
-            uint32_t lz[32], li[32];
+            // list[p] = min(list[p], B[p]), B = this chunk's winners in ascending order: the EP_K smallest keys of both,
+            // rising then falling; slots past `won` hold stale bits: the clamp keeps the read inside S, the value is dropped
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int kb = 31 - i;  // B's partner of A[i]
-                uint32_t bz = 0xFFFFFFFFu, bi = 0xFFFFFFFFu;
-                if (kb < EP_K) {
-                    // slots past `won` hold stale bits: the mask keeps the read inside S, the value is dropped
-                    const uint2 w = *reinterpret_cast<const uint2*>(&S[slots[kb][lane] & (C - 1)]);
-                    bz = (kb < won) ? w.y : 0xFFFFFFFFu;
-                    bi = (kb < won) ? w.x : 0xFFFFFFFFu;
+            for (int p0 = 0; p0 < EP_K; p0 += 10) {  // ten at a time: twenty pending reads would not fit the registers
+#pragma unroll
+                for (int p = p0; p < p0 + 10; ++p) {
+                    const u64 w = lds_key(&S[min((int)slots[p][lane], C - 1)]);
+                    const u64 kb = (p < won) ? w : ~0ull, ka = kl[p];
+                    kl[p] = kb < ka ? kb : ka;
                 }
-                if (i >= EP_K) {
-                    lz[i] = bz;
-                    li[i] = bi;
-                } else if (kb >= EP_K) {
-                    lz[i] = kz[i];
-                    li[i] = ki[i];
-                } else {
-                    const bool lt = make_key(bz, bi) < make_key(kz[i], ki[i]);
-                    lz[i] = lt ? bz : kz[i];
-                    li[i] = lt ? bi : ki[i];
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // bitonic merge for a length that is not a power of two (EP_K = 16 + 4), descending: positions 20 .. 31 would
+            // hold minus infinity and never move, so the exchanges with them are left out
+            static_assert(EP_K == 20, "the merge network is written for 20 entries");
 #pragma unroll
-            for (int j = 16; j >= 1; j >>= 1) {
+            for (int i = 0; i < 4; ++i) ce_desc(kl, i, i + 16);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    if ((i & j) == 0) {
-                        const bool sw = make_key(lz[i | j], li[i | j]) < make_key(lz[i], li[i]);
-                        const uint32_t az = lz[i], ai = li[i];
-                        lz[i] = sw ? lz[i | j] : az;
-                        li[i] = sw ? li[i | j] : ai;
-                        lz[i | j] = sw ? az : lz[i | j];
-                        li[i | j] = sw ? ai : li[i | j];
-                    }
-                }
+            for (int j = 8; j >= 1; j >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((i & j) == 0) ce_desc(kl, i, i | j);
             }
-#pragma unroll
-            for (int k = 0; k < EP_K; ++k) {
-                kz[k] = lz[k];
-                ki[k] = li[k];
-            }
+            ce_desc(kl, 16, 18);
+            ce_desc(kl, 17, 19);
+            ce_desc(kl, 16, 17);
+            ce_desc(kl, 18, 19);
         }
         ++chunk_no;
         if (pos < end) {
@@ -1274,19 +1180,41 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if (inside) {
                 mine = ~0ull;
 #pragma unroll
-                for (int k = 0; k < EP_K; ++k)
-                    if (k == K - 1) mine = make_key(kz[k], ki[k]);
+                for (int p = 0; p < EP_K; ++p)
+                    if (p == EP_K - K) mine = kl[p];
             }
             T = wave_max_u64(mine);
         }
+        EP_STAGE(3)
     }
-    if (DBG != 0 && DBG != 4) return;
-    if (DBG == 4) {  // everything but the compositor
-        if ((kz[0] ^ ki[19]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
+#ifdef EP_TILE_TIMES
+    if (STOP != 0) {
+        if (STOP == 4 && (uint32_t)(kl[0] ^ kl[19]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
         return;
     }
-    if (inside) composite_and_store(g, rp, ndc, kz, ki, xi, yi, xf, yf, d_flags_a, d_flags_b, out);
+#endif
+    fill_color_lut(reinterpret_cast<float*>(S), rp, d_flags_a, d_flags_b, lane);  // S is free now
+    if (inside) {
+        uint32_t az[EP_K], ai[EP_K];  // ascending order for the compositor (a renaming, no data moves)
+#pragma unroll
+        for (int k = 0; k < EP_K; ++k) {
+            az[k] = (uint32_t)(kl[EP_K - 1 - k] >> 32);
+            ai[k] = (uint32_t)kl[EP_K - 1 - k];
+        }
+        // the pixel's position is worked out again from an opaque copy of the lane number, so that the index arithmetic
+        // of the output addresses does not stay in registers across the whole chunk loop
+        int lane2 = lane;
+        asm volatile("" : "+v"(lane2));
+        const int xi2 = txi * EP_TILE + (lane2 & 7), yi2 = tyi * EP_TILE + (lane2 >> 3);
+        composite_and_store<(WPE >= 4 ? 10 : 20)>(g, rp, ndc, az, ai, xi2, yi2, xf, yf, reinterpret_cast<const float*>(S),
+                                                  out);
+    }
 #ifdef EP_TILE_TIMES
+    EP_STAGE(4)
+    if (lane == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[i], stage_cyc[i]);
+        atomicAdd(&g_stage_cycles[5], 1ull);
+    }
     if (lane == 0 && blockIdx.x < 8192u) {
         g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile;
         g_tile_times[blockIdx.x * 4 + 1] = tt_records;
@@ -1340,46 +1268,42 @@ int check_list_size(const ep::RasterGeom& g, int64_t n) {
     return 0;
 }
 
+// The tuning switches a call works with, read once when the call starts (egoprior_set_option may change them from
+// another thread at any time; a call in progress keeps the values it started with).
+struct Tuning {
+    int splat_variant, fill_pieces, bin_lds;
+};
+Tuning read_tuning() {
+    Tuning t;
+    t.splat_variant = ep_host::option("splat_variant");
+    t.fill_pieces = ep_host::option("fill_pieces");
+    t.bin_lds = ep_host::option("bin_lds");
+    return t;
+}
+
+// Workspace layout: header (per-tile words) | pieces table (optional) | tile lists (8-byte entries, the rest).
 struct RasterWs {
     uint32_t* tile_count;   // n_tiles
     uint32_t* tile_start;   // n_tiles + 1
     uint32_t* tile_cursor;  // n_tiles
     uint32_t* tile_order;   // n_tiles
     int32_t* total;         // 1 (+ padding)
-    uint4* list;            // capacity slots of 16 bytes: (point index, depth bits, NDC x, NDC y), or 8-byte entries
-                            // (point index, depth bits) packed at the front
+    uint32_t* pieces;       // workgroups x tiles words: where each counting workgroup's entries start inside each tile's
+                            // list (k_tile_fill_pieces); NULL when that pass is not used
+    uint2* list;            // capacity entries: (point index, depth bits)
     uint64_t capacity;
-    size_t header_bytes;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t raster_header_bytes(int n_tiles) { return align_up(sizeof(uint32_t) * (4 * (size_t)n_tiles + 1 + 16), 256); }
 
-bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, RasterWs& r) {
-    const size_t hb = raster_header_bytes(n_tiles);
-    if (ws == nullptr || bytes < hb + 256) return false;
-    uint32_t* base = (uint32_t*)ws;
-    r.tile_count = base;
-    r.tile_start = base + n_tiles;
-    r.tile_cursor = base + 2 * (size_t)n_tiles + 1;
-    r.tile_order = base + 3 * (size_t)n_tiles + 1;
-    r.total = (int32_t*)(base + 4 * (size_t)n_tiles + 1);
-    r.list = (uint4*)((char*)ws + hb);
-    uint64_t cap = (bytes - hb) / sizeof(uint4);
-    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    r.capacity = cap;
-    r.header_bytes = hb;
-    return true;
-}
-
-// LDS-aggregated binning needs one 32-bit counter per tile in LDS
 // the counting pass aggregates per workgroup in LDS (two 16-bit counters per word) unless option "bin_lds" is 0
 size_t bin_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)((n_tiles + 1) >> 1); }
 // The LDS histogram has 16-bit counters: it is only used while no workgroup can see 65536 points (the grid stops
 // growing at 4096 workgroups, which then loop over several blocks of EP_BIN_PPB points each).
-bool lds_agg_ok(int n_tiles, int64_t n) {
-    return bin_lds_bytes(n_tiles) <= 64 * 1024 && ep_host::option("bin_lds") != 0 &&
+bool lds_agg_possible(int n_tiles, int64_t n) {
+    return bin_lds_bytes(n_tiles) <= 64 * 1024 &&
            (n + EP_BIN_PPB - 1) / EP_BIN_PPB <= (int64_t)4096 * (65535 / EP_BIN_PPB);
 }
 static_assert(EP_BIN_PPB < 65536, "a workgroup's per-tile count must fit into 16 bits");
@@ -1391,23 +1315,38 @@ int bin_grid(int64_t n) {
     return (int)b;
 }
 
-int grid_for(int64_t n, int block) {
-    int64_t b = (n + block - 1) / block;
-    if (b < 1) b = 1;
-    if (b > 8192) b = 8192;
-    return (int)b;
+// bytes of the pieces table for n points (0 when the counting pass cannot aggregate in LDS for this size)
+size_t pieces_bytes(int n_tiles, int64_t n) {
+    if (!lds_agg_possible(n_tiles, n)) return 0;
+    return align_up((size_t)bin_grid(n) * (size_t)n_tiles * sizeof(uint32_t), 256);
 }
 
-// Where the counting pass leaves every workgroup's list offsets for k_tile_fill_pieces: in the upper half of the list
-// slots, which the 8-byte entries of the default splat kernel never reach.  NULL when that variant is not in use, when
-// the counting pass does not aggregate in LDS, or when the table (workgroups x tiles words) does not fit there.
-uint32_t* pieces_table(const RasterWs& w, int n_tiles, int64_t n) {
-    const int variant = ep_host::option("splat_variant");
-    const bool named = (variant >= 1 && variant <= 4) || variant == 6 || variant == 7 || (variant >= 10 && variant <= 16);
-    if (named || ep_host::option("fill_pieces") == 0 || !lds_agg_ok(n_tiles, n)) return nullptr;
-    const uint64_t need = (uint64_t)bin_grid(n) * (uint64_t)n_tiles * sizeof(uint32_t);
-    if (need > (uint64_t)w.capacity * 8ull) return nullptr;
-    return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w.list) + (size_t)w.capacity * 8);
+size_t raster_ws_bytes_for(int n_tiles, int64_t n, uint64_t entries) {
+    return raster_header_bytes(n_tiles) + pieces_bytes(n_tiles, n) + align_up((size_t)entries * sizeof(uint2), 256) + 256;
+}
+
+bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tuning& tn, RasterWs& r) {
+    const size_t hb = raster_header_bytes(n_tiles);
+    if (ws == nullptr || bytes < hb + 256) return false;
+    uint32_t* base = (uint32_t*)ws;
+    r.tile_count = base;
+    r.tile_start = base + n_tiles;
+    r.tile_cursor = base + 2 * (size_t)n_tiles + 1;
+    r.tile_order = base + 3 * (size_t)n_tiles + 1;
+    r.total = (int32_t*)(base + 4 * (size_t)n_tiles + 1);
+    size_t off = hb;
+    r.pieces = nullptr;
+    const size_t pb = pieces_bytes(n_tiles, n);
+    // the table is used when it is wanted and leaves at least as much room for the lists as it takes itself
+    if (pb != 0 && tn.fill_pieces != 0 && tn.bin_lds != 0 && bytes >= hb + 2 * pb + 256) {
+        r.pieces = (uint32_t*)((char*)ws + off);
+        off += pb;
+    }
+    r.list = (uint2*)((char*)ws + off);
+    uint64_t cap = (bytes - off) / sizeof(uint2);
+    if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    r.capacity = cap;
+    return true;
 }
 
 int check_raster_args(const egoprior_raster_params* rp, int H, int W, int64_t n) {
@@ -1425,8 +1364,13 @@ __global__ void k_fill_f32(float* __restrict__ p, size_t n, float v) {
     if (i < n) p[i] = v;
 }
 
+// the number of list entries a frame needs, widened for the caller (tile_start[n_tiles] after k_tile_scan)
+__global__ void k_copy_total(const uint32_t* __restrict__ total, int64_t* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (int64_t)(*total);
+}
+
 // nothing to draw: the frame is the background and every fragment slot is empty
-int clear_outputs(int H, int W, int K, const ep::SplatOut& out, int32_t* d_status, hipStream_t s) {
+int clear_outputs(int H, int W, int K, const ep::SplatOut& out, hipStream_t s) {
     const size_t npix = (size_t)H * (size_t)W;
     bool ok = true;
     if (out.image_u8 != nullptr) ok = ok && hipMemsetAsync(out.image_u8, 0, npix * 3, s) == hipSuccess;
@@ -1441,81 +1385,84 @@ int clear_outputs(int H, int W, int K, const ep::SplatOut& out, int32_t* d_statu
     return ep_host::check_launch("clear_outputs");
 }
 
+// Projection (cam != NULL: [a | b] are world points and the NDC records go to d_ndc; cam == NULL: `a` already holds NDC
+// records) and the per-tile counts.  Zeroes the counters first.
+int launch_count(const egoprior_camera* cam, const ep::RasterGeom& g, const egoprior_point* d_a, int64_t n_a,
+                 const int32_t* d_n_a, const egoprior_point* d_b, int64_t n_b, const int32_t* d_n_b,
+                 egoprior_point* d_ndc, const RasterWs& w, const Tuning& tn, hipStream_t s) {
+    const int n_tiles = g.tiles_x * g.tiles_y;
+    const int64_t n = n_a + n_b;
+    if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
+        return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
+    const bool lds = tn.bin_lds != 0 && lds_agg_possible(n_tiles, n);
+    const size_t shm = lds ? bin_lds_bytes(n_tiles) : 0;
+    uint32_t* const pieces = lds ? w.pieces : nullptr;
+    egoprior_camera cam_unused = {};
+    if (cam != nullptr) {
+        if (lds)
+            EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256), shm, s, *cam, g,
+                      d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1, pieces);
+        else
+            EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n)), dim3(256), 0, s, *cam, g,
+                      d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1, pieces);
+    } else {
+        if (lds)
+            EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256), shm, s,
+                      cam_unused, g, d_a, n_a, d_n_a, (const egoprior_point*)nullptr, (int64_t)0,
+                      (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1, pieces);
+        else
+            EP_LAUNCH("k_project_count", (ep::k_project_count<false, false>), dim3(bin_grid(n)), dim3(256), 0, s,
+                      cam_unused, g, d_a, n_a, d_n_a, (const egoprior_point*)nullptr, (int64_t)0,
+                      (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1, pieces);
+    }
+    return ep_host::check_launch("project_count");
+}
+
 // count (optionally with projection) must already have run into w.tile_count
 int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params* rp, const egoprior_point* d_ndc,
                            int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
-                           const RasterWs& w, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
+                           const RasterWs& w, const Tuning& tn, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
-    // the default splat kernel takes 8-byte list entries (index + depth bits) and fetches x, y from the NDC records once an
-    // entry has passed the threshold filter; the other variants keep the self-contained 16-byte entries
-    const int variant = ep_host::option("splat_variant");
-    const bool named = (variant >= 1 && variant <= 4) || variant == 6 || variant == 7 || (variant >= 10 && variant <= 16);
-    const int list8 = named ? 0 : 1;  // every value without a case of its own below selects the default kernel
-    uint32_t* const pieces = pieces_table(w, n_tiles, n);
-    if (pieces != nullptr)
+    const bool lds = tn.bin_lds != 0 && lds_agg_possible(n_tiles, n);
+    if (lds && w.pieces != nullptr)
         EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
-                  d_ndc, n, d_n, w.tile_start, pieces, reinterpret_cast<uint2*>(w.list), (uint32_t)w.capacity);
+                  d_ndc, n, d_n, w.tile_start, w.pieces, w.list, (uint32_t)w.capacity);
     else
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
-                  w.tile_cursor, w.list, (uint32_t)w.capacity, list8);
+                  w.tile_cursor, w.list, (uint32_t)w.capacity);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
     EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
               w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
-    switch (variant) {
-        case 1:
+    switch (tn.splat_variant) {
+        case 1:  // plain register insertion: the simple cross-check
             EP_LAUNCH("k_splat_bubble", ep::k_splat_bubble, dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc, w.tile_start,
                       w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
             break;
         case 2:  // tiny chunks: forces the multi-chunk path on small inputs (tests)
             EP_SWEEP(64, 64, 2);
             break;
-        case 3:  // larger chunks: faster for a frame on its own, slower with several frames in flight
+        case 3:  // 1024-record chunks, two waves per SIMD
             EP_SWEEP(1024, 1024, 2);
             break;
-        case 7:  // the default geometry with 16-byte list entries (kept for comparison)
+        case 4:  // 384-record chunks, 8.6 KiB of LDS per wave, four waves per SIMD
+            EP_SWEEP(384, 512, 4);
+            break;
+#ifdef EP_TILE_TIMES
+#define EP_PROBE_CASE(v_, stop_)                                                                                  \
+    case v_:                                                                                                       \
+        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 24, stop_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, \
+                  d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);      \
+        break;
+            EP_PROBE_CASE(11, 1)
+            EP_PROBE_CASE(12, 2)
+            EP_PROBE_CASE(13, 3)
+            EP_PROBE_CASE(14, 4)
+#undef EP_PROBE_CASE
+#endif
+        default:  // 512-record chunks, 10.6 KiB of LDS per wave, three waves per SIMD
             EP_SWEEP(512, 512, 3);
-            break;
-        case 4:  // record coordinates as LDS broadcast reads instead of DPP row broadcasts (kept for comparison)
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, false>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
-                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 6:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<1024, 1024, 2, 0, 24, true>), dim3(n_tiles), dim3(64), 0, s, g, *rp,
-                      d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 10:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 1>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 11:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 2>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 12:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 3>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 14:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 5>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 15:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 6>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 16:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 7>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        case 13:
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 4>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,
-                      w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
-            break;
-        default:  // 512-record chunks, 10.6 KiB of LDS per wave, three waves per SIMD; 8-byte list entries
-            EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 0, 24, false, true, true>), dim3(n_tiles), dim3(64), 0, s, g,
-                      *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);
     }
 #undef EP_SWEEP
     return ep_host::check_launch("rasterize");
@@ -1528,11 +1475,23 @@ extern "C" size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t 
     const ep::RasterGeom g = make_geom(H, W, radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     const uint64_t cap = (uint64_t)(n > 0 ? n : 1) * (uint64_t)tiles_per_point_bound(g);
-    return raster_header_bytes(n_tiles) + align_up((size_t)cap * sizeof(uint4), 256) + 256;
+    return raster_ws_bytes_for(n_tiles, n > 0 ? n : 1, cap);
+}
+
+extern "C" size_t egoprior_raster_workspace_bytes_entries(int32_t H, int32_t W, int64_t n, int64_t entries) {
+    if (H <= 0 || W <= 0 || n < 0 || entries < 0) return 0;
+    const int n_tiles = ((W + EP_TILE - 1) / EP_TILE) * ((H + EP_TILE - 1) / EP_TILE);
+    return raster_ws_bytes_for(n_tiles, n > 0 ? n : 1, (uint64_t)entries);
 }
 
 extern "C" size_t egoprior_render_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius) {
     const size_t r = egoprior_raster_workspace_bytes(H, W, n, radius);
+    if (r == 0) return 0;
+    return r + align_up((size_t)(n > 0 ? n : 1) * sizeof(egoprior_point), 256);
+}
+
+extern "C" size_t egoprior_render_workspace_bytes_entries(int32_t H, int32_t W, int64_t n, int64_t entries) {
+    const size_t r = egoprior_raster_workspace_bytes_entries(H, W, n, entries);
     if (r == 0) return 0;
     return r + align_up((size_t)(n > 0 ? n : 1) * sizeof(egoprior_point), 256);
 }
@@ -1564,28 +1523,30 @@ extern "C" int egoprior_rasterize_composite(const egoprior_raster_params* rp, in
     if ((d_zbuf != nullptr || d_dists != nullptr) && d_idx == nullptr)
         return ep_host::fail(EGOPRIOR_E_INVALID, "zbuf/dists need idx");
     hipStream_t s = (hipStream_t)stream;
-    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
+    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     if (int e = check_list_size(g, n)) return e;
+    const Tuning tn = read_tuning();
     RasterWs w;
-    if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, w))
+    if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, n, tn, w))
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "raster workspace too small");
-    if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
-        return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
-    egoprior_camera cam_unused = {};
-    if (lds_agg_ok(n_tiles, n))
-        EP_LAUNCH("k_project_count", (ep::k_project_count<false, true>), dim3(bin_grid(n)), dim3(256),
-                  bin_lds_bytes(n_tiles), s, cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr,
-                  (int64_t)0, (const int32_t*)nullptr, (egoprior_point*)nullptr, w.total, w.tile_count, 1,
-                  pieces_table(w, n_tiles, n));
-    else
-        EP_LAUNCH("k_project_count", (ep::k_project_count<false, false>), dim3(bin_grid(n)), dim3(256), 0, s,
-                  cam_unused, g, d_ndc, n, d_n, (const egoprior_point*)nullptr, (int64_t)0, (const int32_t*)nullptr,
-                  (egoprior_point*)nullptr, w.total, w.tile_count, 1, (uint32_t*)nullptr);
+    if (int e = launch_count(nullptr, g, d_ndc, n, d_n, nullptr, 0, nullptr, nullptr, w, tn, s)) return e;
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
-    return launch_scan_fill_splat(g, rp, d_ndc, n, d_n, d_flags_a, d_flags_b, w, out, d_status, s);
+    return launch_scan_fill_splat(g, rp, d_ndc, n, d_n, d_flags_a, d_flags_b, w, tn, out, d_status, s);
 }
+
+namespace {
+int check_render_args(const egoprior_camera* cam, const egoprior_raster_params* rp, const egoprior_point* d_a,
+                      int64_t n_a, const egoprior_point* d_b, int64_t n_b) {
+    if (cam == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "camera is NULL");
+    if (cam->model != EGOPRIOR_CAM_PINHOLE && cam->model != EGOPRIOR_CAM_FISHEYE)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "unknown camera model");
+    if (n_a < 0 || n_b < 0 || (n_a > 0 && d_a == nullptr) || (n_b > 0 && d_b == nullptr))
+        return ep_host::fail(EGOPRIOR_E_INVALID, "bad cloud pointers / sizes");
+    return check_raster_args(rp, cam->H, cam->W, n_a + n_b);
+}
+}  // namespace
 
 extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_params* rp,
                                      const egoprior_point* d_a, int64_t n_a, const int32_t* d_n_a,
@@ -1593,18 +1554,13 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
                                      const int32_t* d_n_b, const int32_t* d_flags_b, uint8_t* d_image_u8,
                                      float* d_image_f32, int32_t* d_idx, float* d_zbuf, float* d_dists,
                                      int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (cam == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "camera is NULL");
-    if (cam->model != EGOPRIOR_CAM_PINHOLE && cam->model != EGOPRIOR_CAM_FISHEYE)
-        return ep_host::fail(EGOPRIOR_E_INVALID, "unknown camera model");
-    if (n_a < 0 || n_b < 0 || (n_a > 0 && d_a == nullptr) || (n_b > 0 && d_b == nullptr))
-        return ep_host::fail(EGOPRIOR_E_INVALID, "bad cloud pointers / sizes");
+    if (int e = check_render_args(cam, rp, d_a, n_a, d_b, n_b)) return e;
     const int64_t n = n_a + n_b;
-    if (int e = check_raster_args(rp, cam->H, cam->W, n)) return e;
     if ((d_zbuf != nullptr || d_dists != nullptr) && d_idx == nullptr)
         return ep_host::fail(EGOPRIOR_E_INVALID, "zbuf/dists need idx");
     hipStream_t s = (hipStream_t)stream;
     const int H = cam->H, W = cam->W;
-    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, d_status, s);
+    if (n == 0) return clear_outputs(H, W, rp->K, ep::SplatOut{d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists}, s);
     const ep::RasterGeom g = make_geom(H, W, rp->radius);
     const int n_tiles = g.tiles_x * g.tiles_y;
     if (int e = check_list_size(g, n)) return e;
@@ -1612,28 +1568,58 @@ extern "C" int egoprior_render_frame(const egoprior_camera* cam, const egoprior_
     if (d_workspace == nullptr || workspace_bytes < ndc_bytes)
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
     egoprior_point* d_ndc = (egoprior_point*)d_workspace;
+    const Tuning tn = read_tuning();
     RasterWs w;
-    if (!carve_raster_ws((char*)d_workspace + ndc_bytes, workspace_bytes - ndc_bytes, n_tiles, w))
+    if (!carve_raster_ws((char*)d_workspace + ndc_bytes, workspace_bytes - ndc_bytes, n_tiles, n, tn, w))
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "render workspace too small");
-    if (hipMemsetAsync(w.tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s) != hipSuccess)
-        return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
-    if (lds_agg_ok(n_tiles, n))
-        EP_LAUNCH("k_project_count", (ep::k_project_count<true, true>), dim3(bin_grid(n)), dim3(256),
-                  bin_lds_bytes(n_tiles), s, *cam, g, d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc,
-                  w.total, w.tile_count, 1, pieces_table(w, n_tiles, n));
-    else
-        EP_LAUNCH("k_project_count", (ep::k_project_count<true, false>), dim3(bin_grid(n)), dim3(256), 0, s, *cam, g,
-                  d_a, n_a, d_n_a, n_b > 0 ? d_b : nullptr, n_b, d_n_b, d_ndc, w.total, w.tile_count, 1, (uint32_t*)nullptr);
+    if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, d_ndc, w, tn, s)) return e;
     ep::SplatOut out = {d_image_u8, d_image_f32, d_idx, d_zbuf, d_dists};
-    return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, out, d_status, s);
+    return launch_scan_fill_splat(g, rp, d_ndc, n, w.total, d_flags_a, d_flags_b, w, tn, out, d_status, s);
+}
+
+extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const egoprior_raster_params* rp, int32_t H,
+                                           int32_t W, const egoprior_point* d_a, int64_t n_a, const int32_t* d_n_a,
+                                           const egoprior_point* d_b, int64_t n_b, const int32_t* d_n_b,
+                                           int64_t* d_entries, void* d_workspace, size_t workspace_bytes,
+                                           void* stream) {
+    if (d_entries == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "d_entries is NULL");
+    if (cam != nullptr) {
+        if (int e = check_render_args(cam, rp, d_a, n_a, d_b, n_b)) return e;
+        H = cam->H;
+        W = cam->W;
+    } else {
+        if (n_b != 0 || d_b != nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "points in NDC come as one part");
+        if (int e = check_raster_args(rp, H, W, n_a)) return e;
+        if (n_a > 0 && d_a == nullptr) return ep_host::fail(EGOPRIOR_E_INVALID, "d_a is NULL");
+    }
+    const int64_t n = n_a + n_b;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(d_entries, 0, sizeof(int64_t), s) != hipSuccess)
+            return ep_host::fail(EGOPRIOR_E_HIP, "memset failed");
+        return 0;
+    }
+    const ep::RasterGeom g = make_geom(H, W, rp->radius);
+    const int n_tiles = g.tiles_x * g.tiles_y;
+    if (int e = check_list_size(g, n)) return e;
+    Tuning tn = read_tuning();
+    tn.fill_pieces = 0;  // nothing is filled: the header is all this call needs
+    RasterWs w;
+    if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, n, tn, w))
+        return ep_host::fail(EGOPRIOR_E_WORKSPACE, "workspace too small (egoprior_raster_workspace_bytes_entries(H, W, n, 0))");
+    if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, nullptr, w, tn, s)) return e;
+    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
+              w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr);
+    EP_LAUNCH("k_copy_total", k_copy_total, dim3(1), dim3(64), 0, s, w.tile_start + n_tiles, d_entries);
+    return ep_host::check_launch("count_list_entries");
 }
 
 #ifdef EP_TILE_TIMES
-extern "C" int egoprior_debug_chunk_stats(uint32_t* host8, int reset) {
-    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_chunk_stats), 16 * sizeof(uint32_t)) != hipSuccess) return -3;
+extern "C" int egoprior_debug_stage_cycles(unsigned long long* host8, int reset) {
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_stage_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
     if (reset) {
-        uint32_t z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_chunk_stats), z, sizeof(z)) != hipSuccess) return -3;
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -3;
     }
     return 0;
 }
@@ -1641,4 +1627,3 @@ extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_tile_times), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
 }
 #endif
-

@@ -10,7 +10,10 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 CSRC = _PKG.parent / "csrc"
-LIB_PATH = CSRC / "libegoprior_hip.so"
+import os
+
+# EGOPRIOR_LIB: file name of another build of the library in csrc/ (the diagnostic build of the profiling tools)
+LIB_PATH = CSRC / os.environ.get("EGOPRIOR_LIB", "libegoprior_hip.so")
 
 MAX_K = 20
 NOALLOC_MAX_SAMPLES = 8 * 1024 * 1024 + 256 * 1024
@@ -77,6 +80,10 @@ SIGNATURES = {
     "egoprior_rasterize_composite": (C.c_int, [C.POINTER(RasterParams), _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                                _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "egoprior_render_workspace_bytes": (_sz, [_i32, _i32, _i64, _f32]),
+    "egoprior_raster_workspace_bytes_entries": (_sz, [_i32, _i32, _i64, _i64]),
+    "egoprior_render_workspace_bytes_entries": (_sz, [_i32, _i32, _i64, _i64]),
+    "egoprior_count_list_entries": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _i32, _i32, _vp, _i64, _vp,
+                                              _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "egoprior_render_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _vp, _i64, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "egoprior_white_pixel_counts": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),

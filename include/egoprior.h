@@ -186,10 +186,14 @@ int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_
  * Workspace: egoprior_raster_workspace_bytes(H, W, n, radius); a frame whose tile lists outgrow it sets the int32 at
  * d_status to 1 and drops the entries that do not fit.  The word is never cleared by the library (zero it before the
  * first call), so one word can watch over many frames.  The size the query returns reserves, for every point,
- * the largest number of tiles a disc of that radius can overlap, so it cannot overflow for that n.  List positions are
- * 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused with EGOPRIOR_E_INVALID (split the cloud).
+ * the largest number of tiles a disc of that radius can overlap (8 bytes per point-tile pair), so it cannot overflow
+ * for that n.  Any smaller workspace is accepted too (at least egoprior_raster_workspace_bytes_entries(H, W, n, 0)):
+ * the lists then hold what fits and d_status reports the rest; egoprior_count_list_entries gives the exact need of a
+ * frame beforehand.  List positions are 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused
+ * with EGOPRIOR_E_INVALID (split the cloud).
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
+size_t egoprior_raster_workspace_bytes_entries(int32_t H, int32_t W, int64_t n, int64_t entries);
 int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, int32_t W, const egoprior_point* d_ndc,
                                  int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
                                  uint8_t* d_image_u8, float* d_image_f32, int32_t* d_idx, float* d_zbuf,
@@ -205,11 +209,26 @@ int egoprior_rasterize_composite(const egoprior_raster_params* rp, int32_t H, in
  * Workspace: egoprior_render_workspace_bytes(H, W, n_a + n_b, radius).
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_render_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
+size_t egoprior_render_workspace_bytes_entries(int32_t H, int32_t W, int64_t n, int64_t entries);
 int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_params* rp, const egoprior_point* d_a,
                           int64_t n_a, const int32_t* d_n_a, const int32_t* d_flags_a, const egoprior_point* d_b,
                           int64_t n_b, const int32_t* d_n_b, const int32_t* d_flags_b, uint8_t* d_image_u8,
                           float* d_image_f32, int32_t* d_idx, float* d_zbuf, float* d_dists, int32_t* d_status,
                           void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Exact sizing of the tile lists (optional first call of a two-call mode; no counterpart in the reference, whose
+ * pytorch3d rasterizer caps its bins and drops points instead).  Runs the projection (cam != NULL: [a | b] are world
+ * points; cam == NULL: d_a holds n_a NDC records, image size H x W, no part b) and the per-tile counting pass, and
+ * writes the number of list entries the frame needs to the device word d_entries.  After reading it back, a workspace
+ * of egoprior_raster_workspace_bytes_entries / egoprior_render_workspace_bytes_entries (H, W, n, entries) holds that
+ * frame; discs of 40 pixels on a large image would otherwise reserve dozens of tiles per point.
+ * Workspace of this call: egoprior_raster_workspace_bytes_entries(H, W, n, 0).
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_count_list_entries(const egoprior_camera* cam, const egoprior_raster_params* rp, int32_t H, int32_t W,
+                                const egoprior_point* d_a, int64_t n_a, const int32_t* d_n_a,
+                                const egoprior_point* d_b, int64_t n_b, const int32_t* d_n_b, int64_t* d_entries,
+                                void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * White-pixel metric of finished frames, data_preprocess/scripts/postprocess_render_dir.py:17-31 (grey conversion and
@@ -233,12 +252,15 @@ int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32
  * with the device: keep it out of timed regions.
  * --------------------------------------------------------------------------------------------------------------- */
 int egoprior_profile_begin(void);
-/* Process-wide tuning / test switches (no counterpart in the reference): "splat_variant" (0 default sweep kernel with
- * 512-record chunks, 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks to force its multi-chunk
- * path on small inputs, 3 with 1024-record chunks, 6 with sampled bucket boundaries), "fill_pieces" (1 default: the
- * tile lists are filled without global atomics where the counting pass could leave its per-workgroup offsets, 0: always
- * one reservation per run of lanes), "bin_lds" (1 default: the tile
- * counts are aggregated per workgroup in LDS, 0: straight global atomics). */
+/* Process-wide tuning / test switches (no counterpart in the reference; the one piece of state the library keeps
+ * besides the per-thread error text).  Every entry point reads them once when it starts, so a change takes effect with
+ * the next call and never in the middle of one.  "splat_variant": 0 default sweep kernel (512-record chunks, three
+ * waves per SIMD), 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks (forces its multi-chunk path
+ * on small inputs), 3 with 1024-record chunks, 4 with 384-record chunks and four waves per SIMD; every variant returns
+ * the same bits.
+ * "fill_pieces": 1 default: the tile lists are filled without global atomics where the counting pass could leave its
+ * per-workgroup offsets, 0: always one reservation per run of lanes.  "bin_lds": 1 default: the tile counts are
+ * aggregated per workgroup in LDS, 0: straight global atomics. */
 int egoprior_set_option(const char* name, int32_t value);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
                          int32_t* n_kernels);

@@ -185,12 +185,11 @@ def test_project_points(engine, size):
     assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 6, 7],
-                ids=["sweep512-list8", "bubble", "sweep64", "sweep1024", "sweep1024-sampled", "sweep512-list16"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["sweep512", "bubble", "sweep64", "sweep1024", "sweep384"])
 def splat_variant(request):
     """Every splat kernel variant must give the same bits: the default sweep kernel (512-record chunks), the plain
     register-insertion kernel, the sweep kernel with 64-record chunks (forces its multi-chunk merge on these small
-    inputs), with 1024-record chunks, and with sampled instead of equal-width level-1 bucket boundaries."""
+    inputs), with 1024-record chunks and with 384-record chunks (not a power of two, four waves per SIMD)."""
     from egoprior import _lib
     _lib.set_option("splat_variant", request.param)
     yield request.param

@@ -10,8 +10,7 @@ import numpy as np
 import torch
 from egoprior import _lib
 
-_lib.LIB_PATH = _lib.CSRC / ("libegoprior_hip_chunkstats.so" if "--chunks" in sys.argv else "libegoprior_hip_tiletimes.so")
-sys.argv = [a for a in sys.argv if a != "--chunks"]
+_lib.LIB_PATH = _lib.CSRC / "libegoprior_hip_tiletimes.so"
 from egoprior import engine as eng, synth
 
 ps = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
@@ -31,18 +30,17 @@ cam = eng.pinhole_camera(R, t, synth.ego_pinhole_K(He, We), He, We)
 rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
-cs = C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_chunk_stats
-cbuf = (C.c_uint32 * 16)()
+cs = C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_stage_cycles
+cbuf = (C.c_uint64 * 8)()
 cs(cbuf, 1)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
 cs(cbuf, 0)
-c = list(cbuf)
-if c[0]:  # only a build with -DEP_CHUNK_STATS counts these (its atomics distort the wave durations below)
-    print(f"sweep blocks of 64 records, pixel-major: first chunks {c[6]}, later chunks {c[7]}; record-major pixel visits: "
-          f"first {c[8]}, later {c[9]}; open pixels offered per block: first {c[10] / max(c[6] + 1e-9, 1):.1f} "
-          f"(over pixel- and record-major blocks), later total {c[11]}")
-    print(f"chunks {c[0]} (records kept {c[3]}); later chunks {c[1]} (kept {c[4]}), of those unfiltered {c[2]} (kept {c[5]})")
+c = [int(v) for v in cbuf]
+tot = max(sum(c[:5]), 1)
+print("wave cycles by stage (all waves): " + ", ".join(
+    f"{n} {100 * v / tot:.1f}%" for n, v in zip(("load+filter", "sort", "sweep+append", "merge", "compositor"), c[:5]))
+    + f"; total {tot:.4g} over {c[5]} waves")
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()
 assert dbg(buf, 4 * n_tiles) == 0

@@ -364,6 +364,29 @@ class Engine:
 # ----------------------------------------------------------------------------------------------------------------------
 # frames in flight
 # ----------------------------------------------------------------------------------------------------------------------
+def hardware_queues() -> int:
+    """Hardware queues HIP gives this process (GPU_MAX_HW_QUEUES, 4 by default)."""
+    import os
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", "4")))
+    except ValueError:
+        return 4
+
+
+def check_stream_budget(n_slots: int, extra_priorities: Sequence[int] = (), oversubscribe: bool = False) -> None:
+    """Raises ValueError for a frame pipeline whose streams would share hardware queues (more slots than queues) or mix
+    priorities, the two ingredients of the stall described in FramePipeline's docstring."""
+    if oversubscribe:
+        return
+    hwq = hardware_queues()
+    if n_slots > hwq:
+        raise ValueError(f"{n_slots} frames in flight need {n_slots} streams, but this process has {hwq} hardware queues "
+                         "(GPU_MAX_HW_QUEUES): streams that share a queue serialise, event waits included; pass "
+                         "oversubscribe=True to try it anyway")
+    if any(int(p) != 0 for p in extra_priorities):
+        raise ValueError("the frame pipeline takes default-priority streams only (pass oversubscribe=True to override)")
+
+
 class FramePipeline:
     """Renders a sequence of ego frames with several frames in flight on one GPU.
 
@@ -379,14 +402,24 @@ class FramePipeline:
         pipe.finish()          # joins the streams; raises if a tile list overflowed
 
     Inputs and outputs must stay alive and untouched until finish().  Not thread-safe.
+
+    Streams and hardware queues.  A process has GPU_MAX_HW_QUEUES hardware queues (4 unless the environment says
+    otherwise) and HIP multiplexes its streams onto them, so two streams that share a queue run strictly one packet after
+    the other, event-wait packets included.  The pipeline therefore keeps one default-priority stream per slot, lets
+    slots wait only on the main stream (fork, `after_main`) and the main stream on the slots (join), and refuses more
+    slots than hardware queues or streams of another priority unless `oversubscribe=True`: an experiment that gave each
+    slot a second, high-priority stream for its binning kernels (8 slot streams + the default stream on 4 queues, with
+    event waits from a slot's splat stream on its binning stream and back, for the reuse of the slot's workspace) stopped
+    making progress in its warm-up and had to be killed, and more than 4 default-priority slots measured slower than 4.
     """
 
     def __init__(self, engine: Engine, static: DeviceCloud, rp: RasterParams, He: int, We: int,
                  exo_hw: Optional[Sequence[int]] = None, subsample: int = 1, slots: int = 4,
-                 extra_streams: Optional[Sequence["torch.cuda.Stream"]] = None):
+                 extra_streams: Optional[Sequence["torch.cuda.Stream"]] = None, oversubscribe: bool = False):
         self.E, self.L = engine, engine.L
         self.static, self.rp, self.He, self.We = static, rp, int(He), int(We)
         self.n_slots = max(1, int(slots))
+        check_stream_budget(self.n_slots, [getattr(st, "priority", 0) for st in (extra_streams or [])], oversubscribe)
         dev = engine.device
         self.status = torch.zeros(self.n_slots, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):

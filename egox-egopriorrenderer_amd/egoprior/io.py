@@ -19,8 +19,10 @@ quaternion, vipe/utils/geometry.py:339-344, which changes a valid pose by < 1e-6
 """
 from __future__ import annotations
 
+import ctypes as _C
 import io as _io
 import struct
+import threading
 import zipfile
 import zlib
 from dataclasses import dataclass
@@ -76,6 +78,54 @@ class ArtifactPath:
 
 def _twin(path: Path) -> Path:
     return path.with_suffix(".npy")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Native decoders (csrc/egoprior_codec.c): the same two formats as decode_exr_half_z / decode_png_gray below, decoded
+# straight into a caller-owned buffer with the GIL released.  Optional: without the library the Python decoders run.
+# ----------------------------------------------------------------------------------------------------------------------
+_CODEC_PATH = Path(__file__).resolve().parent.parent / "csrc" / "libegoprior_codec.so"
+_codec_lib = None
+_codec_lock = threading.Lock()
+
+
+def native_codec():
+    """The ctypes handle of libegoprior_codec.so, or None when it has not been built."""
+    global _codec_lib
+    if _codec_lib is None:
+        with _codec_lock:
+            if _codec_lib is None:
+                if not _CODEC_PATH.exists():
+                    _codec_lib = False
+                else:
+                    L = _C.CDLL(str(_CODEC_PATH))
+                    i32p = _C.POINTER(_C.c_int32)
+                    for name in ("epc_exr_half_z_size", "epc_png_gray8_size"):
+                        getattr(L, name).argtypes = [_C.c_char_p, _C.c_size_t, i32p, i32p]
+                        getattr(L, name).restype = _C.c_int
+                    for name in ("epc_exr_half_z_decode", "epc_png_gray8_decode"):
+                        getattr(L, name).argtypes = [_C.c_char_p, _C.c_size_t, _C.c_void_p, _C.c_int32, _C.c_int32]
+                        getattr(L, name).restype = _C.c_int
+                    _codec_lib = L
+    return _codec_lib or None
+
+
+def _native_decode(kind: str, buf: bytes, dtype, out: Optional[np.ndarray]):
+    """The decoded (H, W) array (`out` itself when given), or None when the library is missing or declines the file.
+    A given `out` of the wrong shape / dtype / layout is an error of the caller."""
+    L = native_codec()
+    if L is None:
+        return None
+    h, w = _C.c_int32(), _C.c_int32()
+    if getattr(L, f"epc_{kind}_size")(buf, len(buf), _C.byref(h), _C.byref(w)) != 0:
+        return None
+    if out is None:
+        out = np.empty((h.value, w.value), dtype=dtype)
+    elif out.shape != (h.value, w.value) or out.dtype != np.dtype(dtype) or not out.flags.c_contiguous:
+        raise ValueError(f"out must be a C-contiguous ({h.value},{w.value}) {np.dtype(dtype).name} array")
+    if getattr(L, f"epc_{kind}_decode")(buf, len(buf), out.ctypes.data, h.value, w.value) != 0:
+        return None
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -142,9 +192,10 @@ def read_intrinsics_artifacts(intr_file_path: Path, camera_file_path: Optional[P
     return inds, intr, types
 
 
-def read_rgb_artifacts(rgb_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
+def read_rgb_artifacts(rgb_file_path: Path, wanted=None) -> Iterator[tuple[int, np.ndarray]]:
     """Yields (frame index, (H,W,3) uint8).  (The reference yields uint8/255 as float32; the renderer only ever needs
-    the bytes back: (rgb*255).astype(uint8) is the identity on them.)"""
+    the bytes back: (rgb*255).astype(uint8) is the identity on them.)  wanted: a container of frame indices; the other
+    frames yield SKIPPED (a .npy twin is then not even read for them; a video still has to be decoded in order)."""
     rgb_file_path = Path(rgb_file_path)
     if rgb_file_path.exists() and rgb_file_path.suffix != ".npy":
         try:
@@ -156,14 +207,14 @@ def read_rgb_artifacts(rgb_file_path: Path) -> Iterator[tuple[int, np.ndarray]]:
         else:
             reader = imageio.get_reader(rgb_file_path, "ffmpeg")
             for i, frame in enumerate(reader):
-                yield i, np.asarray(frame, dtype=np.uint8)
+                yield i, (SKIPPED if (wanted is not None and i not in wanted) else np.asarray(frame, dtype=np.uint8))
             return
     tw = rgb_file_path if rgb_file_path.suffix == ".npy" else _twin(rgb_file_path)
     if not tw.exists():
         raise FileNotFoundError(str(rgb_file_path))
     arr = np.load(tw, mmap_mode="r")
     for i in range(arr.shape[0]):
-        yield i, np.asarray(arr[i], dtype=np.uint8)
+        yield i, (SKIPPED if (wanted is not None and i not in wanted) else np.asarray(arr[i], dtype=np.uint8))
 
 
 def read_depth_artifacts(zip_file_path: Path, keep_half: bool = False, wanted=None) -> Iterator[tuple[int, np.ndarray]]:
@@ -282,10 +333,35 @@ def _exr_unrle(src: bytes, n_out: int) -> np.ndarray:
     return np.frombuffer(bytes(out), dtype=np.uint8)
 
 
-def decode_exr_half_z(buf: bytes) -> np.ndarray:
+def exr_size(buf: bytes) -> tuple[int, int]:
+    """(H, W) of the data window of an OpenEXR file; OSError like decode_exr_half_z."""
+    L = native_codec()
+    if L is not None:
+        h, w = _C.c_int32(), _C.c_int32()
+        if L.epc_exr_half_z_size(buf, len(buf), _C.byref(h), _C.byref(w)) == 0:
+            return h.value, w.value
+    return decode_exr_half_z(buf, native=False).shape
+
+
+def decode_exr_half_z(buf: bytes, out: Optional[np.ndarray] = None, native: bool = True) -> np.ndarray:
     """(H, W) float16 of channel Z of a single-part scan-line OpenEXR file with compression none, RLE, ZIPS or ZIP.
     Raises OSError for anything that is not such a file (what OpenEXR.InputFile raises, and what the reference's reader
-    catches to substitute an all-NaN frame, vipe/utils/io.py:293-305)."""
+    catches to substitute an all-NaN frame, vipe/utils/io.py:293-305).  out: a C-contiguous (H, W) float16 array to
+    decode into (returned).  native=False forces the Python decoder (the two agree bit for bit; the tests compare them)."""
+    if native:
+        got = _native_decode("exr_half_z", buf, np.float16, out)
+        if got is not None:
+            return got
+    res = _decode_exr_half_z_py(buf)  # also the path that words the error for a file the native decoder declined
+    if out is not None:
+        if out.shape != res.shape or out.dtype != np.float16:
+            raise ValueError(f"out must be a {res.shape} float16 array")
+        out[...] = res
+        return out
+    return res
+
+
+def _decode_exr_half_z_py(buf: bytes) -> np.ndarray:
     try:
         magic, version = struct.unpack_from("<iI", buf, 0)
         if magic != _EXR_MAGIC or (version & 0xFF) != 2 or (version & 0x1A00):  # tiled / deep / multi-part bits
@@ -383,8 +459,24 @@ def encode_exr_half_z(depth: np.ndarray, compression: int = _EXR_ZIP) -> bytes:
     return head + table + b"".join(chunks)
 
 
-def decode_png_gray(buf: bytes) -> np.ndarray:
-    """Minimal PNG decoder: 8- or 16-bit greyscale (colour type 0), non-interlaced."""
+def decode_png_gray(buf: bytes, out: Optional[np.ndarray] = None, native: bool = True) -> np.ndarray:
+    """Minimal PNG decoder: 8- or 16-bit greyscale (colour type 0), non-interlaced.  8-bit files go through the native
+    decoder when it is built (native=False forces the Python one; they agree bit for bit); out: a C-contiguous (H, W)
+    uint8 array to decode an 8-bit file into (returned)."""
+    if native:
+        got = _native_decode("png_gray8", buf, np.uint8, out)
+        if got is not None:
+            return got
+    res = _decode_png_gray_py(buf)
+    if out is not None:
+        if out.shape != res.shape or out.dtype != res.dtype:
+            raise ValueError(f"out must be a {res.shape} {res.dtype.name} array")
+        out[...] = res
+        return out
+    return res
+
+
+def _decode_png_gray_py(buf: bytes) -> np.ndarray:
     if buf[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("not a PNG")
     pos, idat, hdr = 8, [], None

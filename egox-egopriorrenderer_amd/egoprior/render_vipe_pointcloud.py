@@ -183,15 +183,16 @@ class _RayTables:
 
 def _frames(artifact: ArtifactPath, tolerant: bool, wanted=None):
     """One sequential pass over (c2w, rgb, intr, camera type, depth, mask) like the reference's zip(...).  wanted: frame
-    indices whose depth and mask are needed; for the others those two come back as io.SKIPPED, undecoded."""
+    indices whose colour image, depth and mask are needed; for the others those three come back as io.SKIPPED,
+    undecoded where the container allows it."""
     _, poses = read_pose_artifacts(artifact.pose_path)
     _, intr, types = read_intrinsics_artifacts(artifact.intrinsics_path, artifact.camera_type_path)
     depth_it = read_depth_artifacts(artifact.depth_path, keep_half=True, wanted=wanted)  # uploaded as stored
     mask_it = read_instance_artifacts(artifact.mask_path, wanted=wanted)
     if tolerant:
         depth_it, mask_it = _none_after_missing(depth_it), _none_after_missing(mask_it)
-    for c2w, (_, rgb), k, ct, (_, depth), (_, mask) in zip(poses, read_rgb_artifacts(artifact.rgb_path), intr, types,
-                                                         depth_it, mask_it):
+    for c2w, (_, rgb), k, ct, (_, depth), (_, mask) in zip(poses, read_rgb_artifacts(artifact.rgb_path, wanted=wanted),
+                                                         intr, types, depth_it, mask_it):
         yield c2w, rgb, k, ct, depth, mask
 
 

@@ -9,7 +9,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 if __name__ == "__main__":
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # under torchrun the frame-sharded path runs, with one rank too (its collectives then are one-rank collectives)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         from egoprior.distributed import main_distributed
         main_distributed()
     else:

@@ -16,6 +16,27 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(egoprior_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_frame_pipeline_stream_budget():
+    """More frames in flight than hardware queues, or streams of another priority, are refused unless asked for."""
+    import os
+    from egoprior import engine as eng
+    old = os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    try:
+        assert eng.hardware_queues() == 4
+        eng.check_stream_budget(4, [0, 0, 0])
+        with pytest.raises(ValueError, match="hardware queues"):
+            eng.check_stream_budget(5)
+        with pytest.raises(ValueError, match="default-priority"):
+            eng.check_stream_budget(4, [0, -1, 0])
+        eng.check_stream_budget(8, [-1] * 7, oversubscribe=True)
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        eng.check_stream_budget(8)
+    finally:
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        if old is not None:
+            os.environ["GPU_MAX_HW_QUEUES"] = old
+
+
 def test_library_exports_every_declared_symbol():
     import ctypes
     from egoprior import _lib

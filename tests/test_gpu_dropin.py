@@ -284,3 +284,31 @@ def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode):
     else:
         diff = np.abs(a.astype(int) - b.astype(int))
         assert diff.max() <= 2 and (diff > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_onlybg"])
+def test_cli_under_torchrun_with_rccl(clip_dir, tmp_path, mode):
+    """The same CLI path with its real data backend: one rank under torchrun (this box has one GPU), collectives over
+    RCCL, whose communicator is created for the set-up collectives, destroyed before the frames render and created once
+    more for the final gather; control plane on gloo.  One rank = the single-process bits exactly."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from egoprior import render_vipe_pointcloud as rv
+    c = clip_dir
+    argv = ["--input_dir", str(c["base"]), "--meta_json_path", str(c["meta"]), "--point_size", "4.0",
+            "--start_frame", "0", "--end_frame", str(c["F"] - 1)]
+    if mode == "meanbg_fisheye_onlybg":
+        argv += ["--fish_eye_rendering", "--use_mean_bg", "--only_bg", "--online_calibration_path", str(c["calib"])]
+    rv.main(argv + ["--out_dir", str(tmp_path / "one")])
+    script = Path(rv.__file__).resolve().parents[1] / "scripts" / "render_vipe_pointcloud.py"
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", str(script), *argv,
+                          "--out_dir", str(tmp_path / "rccl")], capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, run.stderr[-3000:]
+    one, two = tmp_path / "one" / "take01", tmp_path / "rccl" / "take01"
+    if (one / "ego_Prior.mp4").exists():
+        pytest.skip("mp4 written (imageio present); pixel comparison needs the lossless twin")
+    a, b = np.load(one / "ego_Prior.npy"), np.load(two / "ego_Prior.npy")
+    assert a.shape == b.shape == (c["F"], 448, 448, 3) and a.any()
+    assert np.array_equal(a, b)

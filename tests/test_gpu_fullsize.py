@@ -250,3 +250,60 @@ def test_unproject_4k_exo_frame(engine, select):
     assert np.array_equal(p32, ref_p.astype(np.float32))
     assert cloud.flags.item() == 1
     engine._ws.pop("unproject", None)
+
+
+def test_exact_workspace_sizing_for_large_discs(engine):
+    """point_size 20 on a 1024 x 1024 image: a disc can overlap 49 tiles, so the worst-case workspace of 20 M points is
+    7.8 GB although most points lie outside the image.  The two-call mode counts first (egoprior_count_list_entries), and
+    a workspace sized from that count renders the same bits as the oracle; one entry less and the status word reports
+    the overflow."""
+    import ctypes as C
+    from egoprior import _lib
+    from egoprior import engine as eng
+    L, dev = engine.L, engine.device
+    rng = np.random.default_rng(17)
+    n, S, ps = 20_000_000, 1024, 20.0
+    ndc = np.empty((n, 3), dtype=np.float32)
+    ndc[:, 0] = rng.uniform(-3.0, 3.0, n)
+    ndc[:, 1] = rng.uniform(-3.0, 3.0, n)
+    ndc[:, 2] = rng.uniform(0.5, 50, n)
+    r = O.radius_ndc(ps, S, S)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, S, S, K, "scatter")
+    rec = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+    rec[:, :3] = torch.from_numpy(ndc).to(dev)
+    del ndc
+    rp = eng.make_raster_params(ps, S, S, K=K, colors_gt1=1)
+    worst = L.egoprior_raster_workspace_bytes(S, S, n, rp.radius)
+    ws0 = torch.empty(L.egoprior_raster_workspace_bytes_entries(S, S, n, 0), dtype=torch.uint8, device=dev)
+    entries = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.egoprior_count_list_entries(None, C.byref(rp), S, S, C.c_void_p(rec.data_ptr()), n, None, None, 0, None,
+                                             C.c_void_p(entries.data_ptr()), C.c_void_p(ws0.data_ptr()), ws0.numel(), st))
+    need = int(entries.item())
+    exact = L.egoprior_raster_workspace_bytes_entries(S, S, n, need)
+    assert 0 < need < n * 49 and exact < worst // 4
+    # every tile list entry is a (disc, tile) pair whose rectangle the binning accepted: the count is at least the
+    # number of hits divided by the pixels of a tile
+    assert need >= int((ref_idx >= 0).any(axis=2).sum()) // 64
+
+    def render(nbytes):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        idx = torch.empty((S, S, K), dtype=torch.int32, device=dev)
+        zb = torch.empty((S, S, K), dtype=torch.float32, device=dev)
+        ds = torch.empty((S, S, K), dtype=torch.float32, device=dev)
+        img = torch.empty((S, S, 3), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.egoprior_rasterize_composite(C.byref(rp), S, S, C.c_void_p(rec.data_ptr()), n, None, None, None,
+                                                  C.c_void_p(img.data_ptr()), None, C.c_void_p(idx.data_ptr()),
+                                                  C.c_void_p(zb.data_ptr()), C.c_void_p(ds.data_ptr()),
+                                                  C.c_void_p(status.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        torch.cuda.synchronize()
+        return idx, zb, ds, int(status.item())
+
+    idx, zb, ds, status = render(exact)
+    assert status == 0
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(zb.cpu().numpy(), ref_z)
+    assert np.array_equal(ds.cpu().numpy(), ref_d)
+    _, _, _, status = render(L.egoprior_raster_workspace_bytes_entries(S, S, n, need - 300))
+    assert status == 1  # the lists no longer fit: reported, nothing written out of bounds

@@ -84,6 +84,7 @@ Opt g_opts[] = {
                            // 3: sweep, 1024-record chunks; 4: sweep, 384-record chunks
     {"fill_pieces", 1},    // 1: fill pass without global atomics where possible (k_tile_fill_pieces), 0: always k_tile_fill
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
+    {"slices", 1},         // 1: tiles with very long lists are split over several waves, 0: one wave per tile always
 };
 }  // namespace
 

@@ -225,20 +225,49 @@ __global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, Rast
 // exclusive scan of tile counts; also zeroes the cursors the fill pass bumps, reports list overflow, and writes the
 // launch order of the splat kernel: tiles by decreasing list length (in steps of 16 entries), so that the long tiles
 // start first and the short ones fill the tail of the launch
+// A tile whose list is longer than 2 * EP_SLICE_LEN entries is cut into slices of about EP_SLICE_LEN entries (at most
+// EP_MAX_SLICES of them), each of which a wave of its own reduces to per-pixel lists; the last of these waves to finish
+// merges the lists and shades the tile.  Without this a few hundred heavy tiles of a dense cloud leave most of the GPU idle.
+struct SlicePlan {
+    uint32_t* slot_base;   // n_tiles: first slot of a sliced tile, EP_NO_SLOT for the others
+    uint32_t* done;        // n_tiles: slices of the tile that have finished (sliced tiles only)
+    uint32_t* map;         // max_slots: tile | slice << 24 of every slot
+    uint32_t* total;       // 1: slots in use this launch
+    unsigned long long* partial;  // max_slots x EP_K x 64 keys: the per-pixel lists of every slice, descending
+    uint32_t max_slots;    // 0: slicing is off
+};
+#define EP_SLICE_LEN 16384u
+#define EP_MAX_SLICES 64u
+#define EP_NO_SLOT 0xFFFFFFFFu
+__host__ __device__ __forceinline__ uint32_t slices_for(uint32_t count) {
+    if (count <= 2u * EP_SLICE_LEN) return 1u;
+    const uint32_t ns = (count + EP_SLICE_LEN - 1u) / EP_SLICE_LEN;
+    return ns > EP_MAX_SLICES ? EP_MAX_SLICES : ns;
+}
+// entries of one slice: an equal share, rounded up to whole loads of 64
+__host__ __device__ __forceinline__ uint32_t slice_span(uint32_t count, uint32_t ns) {
+    return (((count + ns - 1u) / ns) + 63u) & ~63u;
+}
+
 __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor,
                                                     uint32_t* __restrict__ tile_order, int n_tiles, uint32_t capacity,
-                                                    int32_t* __restrict__ d_status) {
+                                                    int32_t* __restrict__ d_status, SlicePlan sp) {
     constexpr int PT = 8;  // tiles per thread and pass
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t ohist[256];
+    __shared__ uint32_t want_s;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) {
+        carry_s = 0;
+        want_s = 0;
+    }
     if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
+    uint32_t want = 0;  // slots the heavy tiles among this thread's tiles would take
     for (int base = 0; base < n_tiles; base += 1024 * PT) {
         const int t0 = base + tid * PT;
         uint32_t v[PT];
@@ -265,6 +294,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
             if (t0 + k < n_tiles) {
                 tile_start[t0 + k] = run;
                 tile_cursor[t0 + k] = 0u;
+                if (v[k] > 2u * EP_SLICE_LEN) want += slices_for(v[k]);
                 atomicAdd(&ohist[255u - min(v[k] >> 4, 255u)], 1u);
             }
             run += v[k];
@@ -299,6 +329,56 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     for (int t = tid; t < n_tiles; t += 1024) {
         const uint32_t v = tile_count[t];
         tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
+    }
+    if (sp.max_slots == 0u) return;
+    if (__ballot(want != 0u) != 0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) want += __shfl_xor(want, d);
+        if (lane == 0) atomicAdd(&want_s, want);
+    }
+    __syncthreads();
+    const uint32_t want_all = want_s;
+    const bool slicing = want_all != 0u && want_all <= sp.max_slots;  // all or nothing: the slots are handed out by a scan
+    if (tid == 0) *sp.total = slicing ? want_all : 0u;
+    if (!slicing) return;  // (the per-tile slot words are only read when the total says that there are slices)
+    for (int t = tid; t < n_tiles; t += 1024) sp.slot_base[t] = EP_NO_SLOT;
+    // slots of the sliced tiles: an exclusive scan of their slice counts, in tile order
+    __syncthreads();
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024 * PT) {
+        const int t0 = base + tid * PT;
+        uint32_t v[PT];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const uint32_t ns = (t0 + k < n_tiles) ? slices_for(tile_count[t0 + k]) : 1u;
+            v[k] = ns > 1u ? ns : 0u;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_sums[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w2 = 0; w2 < wid; ++w2) woff += wave_sums[w2];
+        uint32_t run = carry_s + woff + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            if (v[k] != 0u) {
+                sp.slot_base[t0 + k] = run;
+                sp.done[t0 + k] = 0u;
+                for (uint32_t q = 0; q < v[k]; ++q) sp.map[run + q] = (uint32_t)(t0 + k) | (q << 24);
+            }
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
     }
 }
 
@@ -697,6 +777,25 @@ constexpr int next_pow2(int v) {
 // order without any scratch registers.
 // LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space): 8.6 KiB
 // for C = 384, so that four waves per SIMD (16 per CU) fit the 160 KiB of a CU.
+// Sorts a list that rises and then falls (the element-wise minimum of a descending list and an ascending one) back into
+// descending order: a bitonic merge for a length that is not a power of two (EP_K = 16 + 4); positions 20 .. 31 would
+// hold minus infinity and never move, so the exchanges with them are left out.
+__device__ __forceinline__ void merge_network_desc(u64 (&kl)[EP_K]) {
+    static_assert(EP_K == 20, "the merge network is written for 20 entries");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ce_desc(kl, i, i + 16);
+#pragma unroll
+    for (int j = 8; j >= 1; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((i & j) == 0) ce_desc(kl, i, i | j);
+    }
+    ce_desc(kl, 16, 18);
+    ce_desc(kl, 17, 19);
+    ce_desc(kl, 16, 17);
+    ce_desc(kl, 18, 19);
+}
+
 template <int C, int NB, int WPE, int PIXMAJ = 24, int STOP = 0>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
@@ -704,7 +803,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                                                     const uint32_t* __restrict__ tile_order,
                                                     const uint2* __restrict__ list, uint32_t capacity,
                                                     const int32_t* __restrict__ d_flags_a,
-                                                    const int32_t* __restrict__ d_flags_b, SplatOut out) {
+                                                    const int32_t* __restrict__ d_flags_b, SlicePlan sp, SplatOut out) {
     static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 1024 && (NB & (NB - 1)) == 0 && NB >= C, "geometry");
     constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
     constexpr int PER = NB / 64;  // buckets per lane
@@ -716,7 +815,20 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
     uint16_t(*const slots)[64] = reinterpret_cast<uint16_t(*)[64]>(aux);
 
-    const int tile = (int)tile_order[blockIdx.x];
+    // The first sp.max_slots workgroups of the launch take the slices of the heavy tiles (the slots in use come first, the
+    // others leave at once); the rest take one tile each, longest list first, and leave the sliced tiles alone.
+    int tile;
+    uint32_t my_slot = EP_NO_SLOT, n_slices = 1u, slice_no = 0u;
+    if (blockIdx.x < sp.max_slots) {
+        if (blockIdx.x >= *sp.total) return;
+        const uint32_t packed = sp.map[blockIdx.x];
+        tile = (int)(packed & 0xFFFFFFu);
+        slice_no = packed >> 24;
+        my_slot = blockIdx.x;
+    } else {
+        tile = (int)tile_order[blockIdx.x - sp.max_slots];
+        if (sp.max_slots != 0u && *sp.total != 0u && sp.slot_base[tile] != EP_NO_SLOT) return;
+    }
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int lane = threadIdx.x;
     const int xi = txi * EP_TILE + (lane & 7);
@@ -741,6 +853,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     for (int k = 0; k < EP_K; ++k) kl[k] = ~0ull;
     u64 T = ~0ull;  // only keys below T can still enter some pixel's top K
     uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
+    if (my_slot != EP_NO_SLOT) {  // this wave's share of the list
+        const uint32_t count = end - pos;
+        n_slices = slices_for(count);
+        const uint32_t span = slice_span(count, n_slices);
+        pos = min(pos + slice_no * span, end);
+        end = min(pos + span, end);
+    }
     if (end > capacity) end = capacity;
     if (pos > end) pos = end;
     int chunk_no = 0;
@@ -750,42 +869,118 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
 #endif
 
+    // Per-record threshold tables (rebuilt after every merge, read while the next chunk is gathered; they live in `aux`,
+    // which is free between a merge and the next bucket count): rowband[a * 8 + b] is the largest K-th key over the pixel
+    // rows a..b of the tile (all ones while a pixel's list is not full), colband the same for columns.  A record can
+    // only enter the list of a pixel its disc reaches, and min(rowband[rows it reaches], colband[columns it reaches]) is
+    // an upper bound on the K-th keys of those pixels.
+    u64* const rowband = reinterpret_cast<u64*>(aux);
+    u64* const colband = rowband + 64;
+    static_assert(AUXB >= 2 * 64 * 8 + 16 * 8, "threshold tables fit");
+    const float inv_pitch = uniform_f32(0.5f * (float)min(g.W, g.H));           // pixels per NDC unit
+    const float reach_px = uniform_f32(sqrtf(r2) * inv_pitch + 0.01f);          // the margin covers every rounding
+
     while (pos < end) {
-        // ---- load + threshold filter -----------------------------------------------------------------------------
+        // ---- gather: keys that can still matter, batch by batch, until the chunk is full --------------------------
+        // Survivors are staged in S (free until this chunk's scatter) and read back lane-strided, so that the sort and
+        // the sweep below always work on a (nearly) full chunk however few keys of the list pass the thresholds.
         u64 key[RPL];               // depth bits << 32 | point index
         uint32_t rx[RPL], ry[RPL];  // NDC x, y bits
         bool val[RPL];
+        int m = 0;
+        __syncthreads();  // the previous chunk's readers of S are done; the threshold tables are written
+        // One batch: up to nb keys per lane from `pos` on, tested against the thresholds; ok[] marks the survivors, whose
+        // number is returned.  All the loads of a round trip are issued before any of them is used.
+        auto gather_batch = [&](int nb, u64(&k)[RPL], uint32_t(&x)[RPL], uint32_t(&y)[RPL], bool(&ok)[RPL]) -> int {
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) {
-            const uint32_t e = pos + (uint32_t)(u * 64 + lane);
-            val[u] = e < end;
-            // unconditional (clamped): all loads are in flight together; an entry is (index, depth bits) = the key as it is
-            key[u] = reinterpret_cast<const u64*>(list)[val[u] ? e : end - 1u];
+            for (int u = 0; u < RPL; ++u) {
+                const uint32_t e = pos + (uint32_t)(u * 64 + lane);
+                ok[u] = (u < nb) && (e < end);
+                // unconditional (clamped); an entry is (index, depth bits) = the key as it is
+                k[u] = reinterpret_cast<const u64*>(list)[ok[u] ? e : end - 1u];
+            }
+            // second round trip: x, y of the entries that pass the tile's threshold (the others read record 0)
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const bool want = ok[u] && (k[u] < T);
+                const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? (uint32_t)k[u] : 0u].x);
+                x[u] = __float_as_uint(xy.x);
+                y[u] = __float_as_uint(xy.y);
+            }
+            int s = 0;
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const float px = __uint_as_float(x[u]), py = __uint_as_float(y[u]);
+                const float ox = fmaxf(fmaxf(cx_lo - px, px - cx_hi), 0.0f);
+                const float oy = fmaxf(fmaxf(cy_lo - py, py - cy_hi), 0.0f);
+                bool o = ok[u] && (k[u] < T) && !(ox * ox + oy * oy > r2_reach);
+                if (chunk_no > 1) {
+                    // pixel columns / rows of the tile within reach of the disc (column c sits at cx_hi - c * pitch)
+                    const float colf = (cx_hi - px) * inv_pitch, rowf = (cy_hi - py) * inv_pitch;
+                    const int xa = max((int)ceilf(colf - reach_px), 0), xb = min((int)floorf(colf + reach_px), 7);
+                    const int ya = max((int)ceilf(rowf - reach_px), 0), yb = min((int)floorf(rowf + reach_px), 7);
+                    o = o && xa <= xb && ya <= yb;
+                    const u64 tr = rowband[o ? ya * 8 + yb : 0], tc = colband[o ? xa * 8 + xb : 0];
+                    o = o && k[u] < (tr < tc ? tr : tc);
+                }
+                ok[u] = o;
+                s += __popcll(__ballot(o));
+            }
+            return s;
+        };
+        auto stage_batch = [&](const u64(&k)[RPL], const uint32_t(&x)[RPL], const uint32_t(&y)[RPL], const bool(&ok)[RPL]) {
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const u64 bal = __ballot(ok[u]);
+                if (ok[u]) {
+                    const int dst = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    S[dst] = make_uint4((uint32_t)k[u], (uint32_t)(k[u] >> 32), x[u], y[u]);
+                }
+                m += __popcll(bal);
+            }
+        };
+        const int s0 = gather_batch(RPL, key, rx, ry, val);
+        pos += C;
+        if (pos >= end || s0 > C - 64) {
+            // the batch ends the list or (nearly) fills the chunk by itself: it is sorted straight from the registers
+            m = s0;
+        } else {
+            stage_batch(key, rx, ry, val);
+            while (pos < end) {
+                const int nb = (int)uniform_u32((uint32_t)((C - m) >> 6));  // keys per lane that still fit
+                if (nb == 0) break;
+                u64 k2[RPL];
+                uint32_t x2[RPL], y2[RPL];
+                bool ok2[RPL];
+                gather_batch(nb, k2, x2, y2, ok2);
+                stage_batch(k2, x2, y2, ok2);
+                pos += (uint32_t)nb * 64u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const int i = u * 64 + lane;
+                val[u] = i < m;
+                const uint4 rec = S[val[u] ? i : 0];
+                key[u] = make_key(rec.y, rec.x);
+                rx[u] = rec.z;
+                ry[u] = rec.w;
+            }
         }
-        // second round trip: x, y of the entries that pass the threshold (the others read record 0)
-#pragma unroll
-        for (int u = 0; u < RPL; ++u) {
-            const bool want = val[u] && (key[u] < T);
-            const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? (uint32_t)key[u] : 0u].x);
-            rx[u] = __float_as_uint(xy.x);
-            ry[u] = __float_as_uint(xy.y);
+        if (m == 0) {
+            if (pos < end) continue;
+            break;
         }
         u64 kmin = ~0ull, kmax = 0ull;
-        int m = 0;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            const float px = __uint_as_float(rx[u]), py = __uint_as_float(ry[u]);
-            const float ox = fmaxf(fmaxf(cx_lo - px, px - cx_hi), 0.0f), oy = fmaxf(fmaxf(cy_lo - py, py - cy_hi), 0.0f);
-            val[u] = val[u] && (key[u] < T) && !(ox * ox + oy * oy > r2_reach);
             const u64 klo = val[u] ? key[u] : ~0ull, khi = val[u] ? key[u] : 0ull;
             kmin = klo < kmin ? klo : kmin;
             kmax = khi > kmax ? khi : kmax;
-            m += __popcll(__ballot(val[u]));
         }
-        pos += C;
         EP_STAGE(0)
         EP_PROBE(1, (uint32_t)key[0] ^ rx[0] ^ ry[RPL - 1] ^ (uint32_t)m)
-        if (m == 0) continue;
         kmin = wave_min_u64(kmin);
         kmax = wave_max_u64(kmax);
         // Two-level monotone bucket map.  Level 1: NB equal-width ranges of [kmin, kmax].  Their histogram, and then the
@@ -1158,21 +1353,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // bitonic merge for a length that is not a power of two (EP_K = 16 + 4), descending: positions 20 .. 31 would
-            // hold minus infinity and never move, so the exchanges with them are left out
-            static_assert(EP_K == 20, "the merge network is written for 20 entries");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ce_desc(kl, i, i + 16);
-#pragma unroll
-            for (int j = 8; j >= 1; j >>= 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if ((i & j) == 0) ce_desc(kl, i, i | j);
-            }
-            ce_desc(kl, 16, 18);
-            ce_desc(kl, 17, 19);
-            ce_desc(kl, 16, 17);
-            ce_desc(kl, 18, 19);
+            merge_network_desc(kl);
         }
         ++chunk_no;
         if (pos < end) {
@@ -1185,6 +1366,40 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
             T = wave_max_u64(mine);
         }
+        if (pos < end && chunk_no > 1) {
+            // threshold tables for the next gather: row / column maxima of the K-th keys, then every band of them
+            u64 mine = 0ull;
+            if (inside) {
+                mine = ~0ull;
+#pragma unroll
+                for (int p = 0; p < EP_K; ++p)
+                    if (p == EP_K - K) mine = kl[p];
+            }
+            u64 rmax = mine, cmax = mine;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) {
+                const u64 o = __shfl_xor(rmax, d);
+                rmax = o > rmax ? o : rmax;
+            }
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1) {
+                const u64 o = __shfl_xor(cmax, d);
+                cmax = o > cmax ? o : cmax;
+            }
+            u64* const line = colband + 64;  // 8 row maxima, 8 column maxima
+            __syncthreads();                 // the merge's reads of the slot lists are done
+            if ((lane & 7) == 0) line[lane >> 3] = rmax;
+            if (lane < 8) line[8 + lane] = cmax;
+            __syncthreads();
+            u64 rb = 0ull, cb = 0ull;
+            for (int i = lane >> 3; i <= (lane & 7); ++i) {
+                const u64 a = line[i], b = line[8 + i];
+                rb = a > rb ? a : rb;
+                cb = b > cb ? b : cb;
+            }
+            rowband[lane] = rb;
+            colband[lane] = cb;
+        }
         EP_STAGE(3)
     }
 #ifdef EP_TILE_TIMES
@@ -1193,6 +1408,34 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         return;
     }
 #endif
+    if (my_slot != EP_NO_SLOT) {
+        // Hand this slice's lists over; the wave that finds all the others already there merges them and goes on.
+        u64* const mine_p = sp.partial + (size_t)my_slot * (EP_K * 64) + lane;
+#pragma unroll
+        for (int k = 0; k < EP_K; ++k) mine_p[k * 64] = kl[k];
+        __threadfence();  // the lists are visible to the device before the arrival is counted
+        uint32_t before = 0u;
+        if (lane == 0) before = atomicAdd(&sp.done[tile], 1u);
+        before = uniform_u32(before);
+        if (before != n_slices - 1u) return;
+        __threadfence();  // and the others' lists are read only after their arrivals have been seen
+        const uint32_t first = sp.slot_base[tile];
+        for (uint32_t o = 0; o < n_slices; ++o) {
+            if (first + o == my_slot) continue;
+            const u64* const theirs = sp.partial + (size_t)(first + o) * (EP_K * 64) + lane;
+            // their list is descending like ours: read back to front it is the ascending sequence the merge wants
+#pragma unroll
+            for (int p0 = 0; p0 < EP_K; p0 += 10) {
+#pragma unroll
+                for (int p = p0; p < p0 + 10; ++p) {
+                    const u64 kb = __builtin_nontemporal_load(&theirs[(EP_K - 1 - p) * 64]), ka = kl[p];
+                    kl[p] = kb < ka ? kb : ka;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            merge_network_desc(kl);
+        }
+    }
     fill_color_lut(reinterpret_cast<float*>(S), rp, d_flags_a, d_flags_b, lane);  // S is free now
     if (inside) {
         uint32_t az[EP_K], ai[EP_K];  // ascending order for the compositor (a renaming, no data moves)
@@ -1216,7 +1459,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         atomicAdd(&g_stage_cycles[5], 1ull);
     }
     if (lane == 0 && blockIdx.x < 8192u) {
-        g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile;
+        g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile | (slice_no << 24);
         g_tile_times[blockIdx.x * 4 + 1] = tt_records;
         g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);
         g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;
@@ -1271,17 +1514,21 @@ int check_list_size(const ep::RasterGeom& g, int64_t n) {
 // The tuning switches a call works with, read once when the call starts (egoprior_set_option may change them from
 // another thread at any time; a call in progress keeps the values it started with).
 struct Tuning {
-    int splat_variant, fill_pieces, bin_lds;
+    int splat_variant, fill_pieces, bin_lds, slices;
 };
 Tuning read_tuning() {
     Tuning t;
     t.splat_variant = ep_host::option("splat_variant");
     t.fill_pieces = ep_host::option("fill_pieces");
     t.bin_lds = ep_host::option("bin_lds");
+    t.slices = ep_host::option("slices");
     return t;
 }
 
-// Workspace layout: header (per-tile words) | pieces table (optional) | tile lists (8-byte entries, the rest).
+// Workspace layout: header (per-tile words) | pieces table (optional) | tile lists (8-byte entries) | slice area
+// (per-tile slot words, slot map, per-slice pixel lists).  Lists and slice area share what the header and the pieces
+// table leave: the lists get the largest capacity whose slice area (enough slots for any distribution of that many
+// entries) still fits.
 struct RasterWs {
     uint32_t* tile_count;   // n_tiles
     uint32_t* tile_start;   // n_tiles + 1
@@ -1292,7 +1539,18 @@ struct RasterWs {
                             // list (k_tile_fill_pieces); NULL when that pass is not used
     uint2* list;            // capacity entries: (point index, depth bits)
     uint64_t capacity;
+    ep::SlicePlan slices;   // max_slots == 0: the workspace has no room for it
 };
+
+// Slots that `entries` list entries can need at most: a sliced tile has more than 2 * EP_SLICE_LEN entries and takes
+// ceil(entries of the tile / EP_SLICE_LEN) slots, fewer than 1.5 slots per EP_SLICE_LEN entries.
+uint64_t slice_slots_for(uint64_t entries) { return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2; }
+constexpr size_t kSlotBytes = (size_t)EP_K * 64 * sizeof(unsigned long long);
+size_t slice_area_bytes(int n_tiles, uint64_t entries) {
+    const uint64_t slots = slice_slots_for(entries);
+    return (sizeof(uint32_t) * (2 * (size_t)n_tiles + 64) + 255) / 256 * 256 + (sizeof(uint32_t) * slots + 255) / 256 * 256 +
+           kSlotBytes * slots;
+}
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1322,7 +1580,8 @@ size_t pieces_bytes(int n_tiles, int64_t n) {
 }
 
 size_t raster_ws_bytes_for(int n_tiles, int64_t n, uint64_t entries) {
-    return raster_header_bytes(n_tiles) + pieces_bytes(n_tiles, n) + align_up((size_t)entries * sizeof(uint2), 256) + 256;
+    return raster_header_bytes(n_tiles) + pieces_bytes(n_tiles, n) + align_up((size_t)entries * sizeof(uint2), 256) +
+           slice_area_bytes(n_tiles, entries) + 256;
 }
 
 bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tuning& tn, RasterWs& r) {
@@ -1343,8 +1602,35 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
         off += pb;
     }
     r.list = (uint2*)((char*)ws + off);
-    uint64_t cap = (bytes - off) / sizeof(uint2);
+    const size_t rest = bytes - off;
+    uint64_t cap = rest / sizeof(uint2);
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+    r.slices = ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (tn.slices != 0 && tn.splat_variant != 1) {
+        // largest capacity whose lists and slice area both fit (the need grows with the capacity: bisection)
+        auto need = [&](uint64_t c) { return align_up((size_t)c * sizeof(uint2), 256) + slice_area_bytes(n_tiles, c); };
+        if (need(64) <= rest) {
+            uint64_t lo = 64, hi = cap;  // need(lo) fits
+            while (lo < hi) {
+                const uint64_t mid = lo + (hi - lo + 1) / 2;
+                if (need(mid) <= rest)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            cap = lo;
+            const uint64_t slots = slice_slots_for(cap);
+            char* q = (char*)ws + off + align_up((size_t)cap * sizeof(uint2), 256);
+            r.slices.slot_base = (uint32_t*)q;
+            r.slices.done = r.slices.slot_base + n_tiles;
+            r.slices.total = r.slices.done + n_tiles;
+            q += align_up(sizeof(uint32_t) * (2 * (size_t)n_tiles + 64), 256);
+            r.slices.map = (uint32_t*)q;
+            q += align_up(sizeof(uint32_t) * slots, 256);
+            r.slices.partial = (unsigned long long*)q;
+            r.slices.max_slots = (uint32_t)(slots > 0x00FFFFFFull ? 0x00FFFFFFull : slots);
+        }
+    }
     r.capacity = cap;
     return true;
 }
@@ -1424,7 +1710,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                            const RasterWs& w, const Tuning& tn, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
-              w.tile_order, n_tiles, (uint32_t)w.capacity, d_status);
+              w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
     const bool lds = tn.bin_lds != 0 && lds_agg_possible(n_tiles, n);
     if (lds && w.pieces != nullptr)
         EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
@@ -1433,8 +1719,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
                   w.tile_cursor, w.list, (uint32_t)w.capacity);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
-    EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc,   \
-              w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out)
+    EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles + w.slices.max_slots), dim3(64), 0, s, g, \
+              *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, w.slices, out)
     switch (tn.splat_variant) {
         case 1:  // plain register insertion: the simple cross-check
             EP_LAUNCH("k_splat_bubble", ep::k_splat_bubble, dim3(n_tiles), dim3(64), 0, s, g, *rp, d_ndc, w.tile_start,
@@ -1452,8 +1738,9 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
 #ifdef EP_TILE_TIMES
 #define EP_PROBE_CASE(v_, stop_)                                                                                  \
     case v_:                                                                                                       \
-        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 24, stop_>), dim3(n_tiles), dim3(64), 0, s, g, *rp, \
-                  d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, out);      \
+        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 24, stop_>), dim3(n_tiles + w.slices.max_slots),    \
+                  dim3(64), 0, s, g, *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a,  \
+                  d_flags_b, w.slices, out);                                                                         \
         break;
             EP_PROBE_CASE(11, 1)
             EP_PROBE_CASE(12, 2)
@@ -1604,12 +1891,14 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
     if (int e = check_list_size(g, n)) return e;
     Tuning tn = read_tuning();
     tn.fill_pieces = 0;  // nothing is filled: the header is all this call needs
+    tn.slices = 0;
     RasterWs w;
     if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, n, tn, w))
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "workspace too small (egoprior_raster_workspace_bytes_entries(H, W, n, 0))");
     if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, nullptr, w, tn, s)) return e;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
-              w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr);
+              w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr,
+              ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
     EP_LAUNCH("k_copy_total", k_copy_total, dim3(1), dim3(64), 0, s, w.tile_start + n_tiles, d_entries);
     return ep_host::check_launch("count_list_entries");
 }

@@ -343,6 +343,33 @@ def exr_size(buf: bytes) -> tuple[int, int]:
     return decode_exr_half_z(buf, native=False).shape
 
 
+def _exr_rle(src: bytes) -> bytes:
+    """The inverse of _exr_unrle (runs of 3..128 equal bytes as a run, everything else as literal stretches <= 127)."""
+    out, i, n = bytearray(), 0, len(src)
+    lit = bytearray()
+
+    def flush():
+        for k in range(0, len(lit), 127):
+            part = lit[k:k + 127]
+            out.append(256 - len(part))
+            out.extend(part)
+        lit.clear()
+
+    while i < n:
+        j = i
+        while j < n and j - i < 128 and src[j] == src[i]:
+            j += 1
+        if j - i >= 3:
+            flush()
+            out.append(j - i - 1)
+            out.append(src[i])
+        else:
+            lit.extend(src[i:j])
+        i = j
+    flush()
+    return bytes(out)
+
+
 def decode_exr_half_z(buf: bytes, out: Optional[np.ndarray] = None, native: bool = True) -> np.ndarray:
     """(H, W) float16 of channel Z of a single-part scan-line OpenEXR file with compression none, RLE, ZIPS or ZIP.
     Raises OSError for anything that is not such a file (what OpenEXR.InputFile raises, and what the reference's reader
@@ -447,8 +474,12 @@ def encode_exr_half_z(depth: np.ndarray, compression: int = _EXR_ZIP) -> bytes:
             packed = zlib.compress(_exr_filter(raw).tobytes())
             if len(packed) < len(data):
                 data = packed
+        elif compression == _EXR_RLE:
+            packed = _exr_rle(_exr_filter(raw).tobytes())
+            if len(packed) < len(data):
+                data = packed
         elif compression != _EXR_NO:
-            raise ValueError("the writer knows compression none, ZIPS and ZIP")
+            raise ValueError("the writer knows compression none, RLE, ZIPS and ZIP")
         chunks.append(struct.pack("<ii", y, len(data)) + data)
     table_at = len(head)
     pos = table_at + 8 * len(chunks)
@@ -538,21 +569,22 @@ def _decode_png_gray_py(buf: bytes) -> np.ndarray:
     return out
 
 
+def decode_instance_png(data: bytes) -> np.ndarray:
+    """One member of the mask archive as (H, W) uint8: OpenCV's decoder when it is importable (what the reference calls,
+    vipe/utils/io.py:325), otherwise the built-in greyscale decoders."""
+    try:
+        import cv2
+    except ImportError:
+        return decode_png_gray(data).astype(np.uint8)
+    return np.asarray(cv2.imdecode(np.frombuffer(data, dtype=np.uint8), cv2.IMREAD_UNCHANGED)).astype(np.uint8)
+
+
 def read_instance_artifacts(zip_file_path: Path, wanted=None) -> Iterator[tuple[int, np.ndarray]]:
     """Yields (frame index, (H,W) uint8 instance ids), 0 = background."""
     zip_file_path = Path(zip_file_path)
     if zip_file_path.exists():
-        try:
-            import cv2
-        except ImportError:
-            cv2 = None
-        def decode(data):
-            if cv2 is not None:
-                return np.asarray(cv2.imdecode(np.frombuffer(data, dtype=np.uint8), cv2.IMREAD_UNCHANGED)).astype(np.uint8)
-            return decode_png_gray(data).astype(np.uint8)
-
         with zipfile.ZipFile(zip_file_path, "r") as z:
-            for name, m in _decode_ahead(z, sorted(z.namelist()), decode, wanted=wanted):
+            for name, m in _decode_ahead(z, sorted(z.namelist()), decode_instance_png, wanted=wanted):
                 if m is SKIPPED:
                     yield int(name.split(".")[0]), SKIPPED
                     continue

@@ -199,14 +199,12 @@ def _frames(artifact: ArtifactPath, tolerant: bool, wanted=None):
 # ----------------------------------------------------------------------------------------------------------------------
 # cloud builders
 # ----------------------------------------------------------------------------------------------------------------------
-def build_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray, spatial_subsample: int = 2):
-    """Static cloud accumulated over all frames: (points (N,3) float64, colours (N,3) uint8, (H,W), T_cam_to_world) --
-    a 4-tuple on success like the reference (:449); 3-tuple with empty arrays when no frame has depth (:452-456)."""
+def _accumulated_background_clouds(frames, T_cam_to_world, spatial_subsample: int, want_xyz64: bool):
+    """Device half of build_background_pointcloud: (one static cloud per frame that has depth, (H,W) or None)."""
     E = _engine()
-    artifact = _first_artifact(input_dir)
-    pts, cols, image_size = [], [], None
+    clouds, image_size = [], None
     tables, first = _RayTables(), None
-    for c2w, rgb, intr, ct, depth, mask in _frames(artifact, tolerant=True):
+    for c2w, rgb, intr, ct, depth, mask in frames:
         if depth is None:
             continue
         if image_size is None:
@@ -214,8 +212,33 @@ def build_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray, spat
         if first is None:
             first = (intr, ct)  # the ray table is built once, from the first usable frame (reference :384)
         rays = tables.get(first[1], first[0], depth.shape[0], depth.shape[1], spatial_subsample)
-        cloud = E.unproject_frame(depth, rgb, mask, first[0], c2w, T_cam_to_world, subsample=spatial_subsample,
-                                  select=_lib.SELECT_STATIC, want_xyz64=True, rays=rays)
+        clouds.append(E.unproject_frame(depth, rgb, mask, first[0], c2w, T_cam_to_world, subsample=spatial_subsample,
+                                        select=_lib.SELECT_STATIC, want_xyz64=want_xyz64, rays=rays))
+    return clouds, image_size
+
+
+def _concat_clouds(clouds):
+    """One device cloud holding the live points of `clouds` in order (one host synchronisation for all the counts)."""
+    import torch
+    E = _engine()
+    counts = torch.cat([c.count for c in clouds]).cpu().tolist()
+    out = E.new_cloud(sum(counts))
+    if sum(counts):
+        torch.cat([c.points[:n] for c, n in zip(clouds, counts)], out=out.points)
+    out.count.fill_(sum(counts))
+    # "some colour byte exceeds 1" (the renderers' divide-by-255 rule, :812-815) holds for the whole when it holds for a part
+    out.flags.copy_(torch.cat([c.flags for c, n in zip(clouds, counts) if n] or [out.flags]).max().reshape(1))
+    return out
+
+
+def build_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray, spatial_subsample: int = 2):
+    """Static cloud accumulated over all frames: (points (N,3) float64, colours (N,3) uint8, (H,W), T_cam_to_world) --
+    a 4-tuple on success like the reference (:449); 3-tuple with empty arrays when no frame has depth (:452-456)."""
+    artifact = _first_artifact(input_dir)
+    clouds, image_size = _accumulated_background_clouds(_frames(artifact, tolerant=True), T_cam_to_world,
+                                                        spatial_subsample, want_xyz64=True)
+    pts, cols = [], []
+    for cloud in clouds:
         n = cloud.n()
         pts.append(cloud.xyz64[:n].cpu().numpy())
         cols.append(cloud.to_numpy()[1])
@@ -236,11 +259,22 @@ def build_mean_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray,
                                      max_frames: int = None):
     """Static cloud from the per-pixel NaN-aware mean over frames: (points (N,3) float64, colours (N,3) uint8, (H,W)).
     Frames stream through a 17-plane accumulator in HBM instead of being stacked (the reference holds 16*F*H*W bytes)."""
-    E = _engine()
     artifact = _first_artifact(input_dir)
+    cloud, image_size = _mean_background_cloud(_frames(artifact, tolerant=True), T_cam_to_world, spatial_subsample,
+                                               max_frames, want_xyz64=True)
+    if cloud is None:
+        logger.warning("No valid background frames found.")
+        return np.empty((0, 3)), np.empty((0, 3)), image_size
+    n = cloud.n()
+    return cloud.xyz64[:n].cpu().numpy(), cloud.to_numpy()[1], image_size
+
+
+def _mean_background_cloud(frames, T_cam_to_world, spatial_subsample: int, max_frames, want_xyz64: bool):
+    """Device half of build_mean_background_pointcloud: (cloud or None when no frame has depth, (H,W) or None)."""
+    E = _engine()
     state, image_size, n_used = None, None, 0
     first = None
-    for c2w, rgb, intr, ct, depth, mask in _frames(artifact, tolerant=True):
+    for c2w, rgb, intr, ct, depth, mask in frames:
         if first is None:
             first = (c2w, intr, ct)
         if depth is None:
@@ -253,15 +287,13 @@ def build_mean_background_pointcloud(input_dir: str, T_cam_to_world: np.ndarray,
         E.meanbg_accumulate(state, depth, rgb, mask, n_used)
         n_used += 1
     if state is None:
-        logger.warning("No valid background frames found.")
-        return np.empty((0, 3)), np.empty((0, 3)), image_size
+        return None, image_size
     c2w, intr, ct = first
     mean_d, mean_c = E.meanbg_finalize(state)
     rays = _RayTables().get(ct, intr, mean_d.shape[0], mean_d.shape[1], spatial_subsample)
     cloud = E.unproject_frame(mean_d, mean_c, None, intr, c2w, T_cam_to_world, subsample=spatial_subsample,
-                              select=_lib.SELECT_ALL, want_xyz64=True, rays=rays)
-    n = cloud.n()
-    return cloud.xyz64[:n].cpu().numpy(), cloud.to_numpy()[1], image_size
+                              select=_lib.SELECT_ALL, want_xyz64=want_xyz64, rays=rays)
+    return cloud, image_size
 
 
 def build_dynamic_points_for_frame(artifact_path: ArtifactPath, frame_idx: int, T_cam_to_world: np.ndarray,
@@ -398,17 +430,23 @@ def project_points_to_image_sequential(bg_points_3d: np.ndarray, bg_colors: np.n
     num_frames = len(ego_extrinsics_list)
     if len(bg_points_3d) == 0 and artifact_path is None:
         return [np.zeros((height, width, 3), dtype=np.uint8) for _ in range(num_frames)]
+    coeffs, aria_size = _lens_setup(use_fisheye, online_calibration_path, original_image_size)
+    bg = _upload(bg_points_3d, bg_colors)  # uploaded and filtered once; the filters are per point
+    want_dyn = (not only_bg) and artifact_path is not None and T_cam_to_world is not None
+    frames = _frames(artifact_path, tolerant=False) if want_dyn else None
+    return _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size, point_size, use_fisheye,
+                            coeffs, aria_size, T_cam_to_world)
+
+
+def _lens_setup(use_fisheye, online_calibration_path, original_image_size):
+    """((radial, tangential, thin prism, focal, principal point), Aria sensor size) of the frame loop (:1142-1160)."""
     aria_size = original_image_size if original_image_size is not None else (2880, 2880)
     rad = tan = thin = foc = pp = None
     if use_fisheye:
         rad, tan, thin, foc, pp = load_aria_distortion_coeffs(online_calibration_path, frame_idx=0)
         if rad is None or tan is None or thin is None:
             raise ValueError("Failed to load distortion coefficients.")
-    bg = _upload(bg_points_3d, bg_colors)  # uploaded and filtered once; the filters are per point
-    want_dyn = (not only_bg) and artifact_path is not None and T_cam_to_world is not None
-    frames = _frames(artifact_path, tolerant=False) if want_dyn else None
-    return _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size, point_size, use_fisheye,
-                            (rad, tan, thin, foc, pp), aria_size, T_cam_to_world)
+    return (rad, tan, thin, foc, pp), aria_size
 
 
 def _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size, point_size, use_fisheye, coeffs,
@@ -480,7 +518,8 @@ def _render_sequence(bg, frames, ego_extrinsics_list, ego_intrinsics, image_size
                                       exo_hw=tuple(dyn_in[0].shape) if dyn_in is not None else None, subsample=2)
             images = torch.empty((num_frames,) + tuple(pipe.image_shape), dtype=torch.uint8, device=E.device)
         if dyn_in is not None:
-            keep.append(dyn_in)
+            if not (isinstance(depth, torch.Tensor) and depth.is_cuda):  # frames of a resident clip outlive the loop
+                keep.append(dyn_in)
             pipe.submit(cam, images[frame_idx], up=dyn_in[3], depth=dyn_in[0], rgb=dyn_in[1], mask=dyn_in[2],
                         after_main=True, rays=dyn_in[4])
         else:
@@ -564,22 +603,44 @@ def main(argv=None):
     os.makedirs(args.out_dir, exist_ok=True)
     _, exo_extrinsic, ego_intrinsic, ego_list = load_camera_params_from_meta(args.meta_json_path, args.input_dir)
     T_cam_to_world = np.linalg.inv(exo_extrinsic)
-    if args.use_mean_bg:
-        res = build_mean_background_pointcloud(args.input_dir, T_cam_to_world)
-    else:
-        res = build_background_pointcloud(args.input_dir, T_cam_to_world)
-    bg_pts, bg_cols = res[0], res[1]
-    if len(bg_pts) == 0:
-        logger.error("No points in background point cloud. Exiting.")
-        return
     fixed_image_size = (448, 448)
-    validate_frame_range(args, len(ego_list), args.input_dir)
-    arts = list(ArtifactPath.glob_artifacts(Path(args.input_dir), use_video=True))
-    frames = project_points_to_image_sequential(
-        bg_pts, bg_cols, ego_list[args.start_frame:args.end_frame + 1], ego_intrinsic, fixed_image_size,
-        args.point_size, use_fisheye=args.fish_eye_rendering, online_calibration_path=args.online_calibration_path,
-        original_image_size=(2880, 2880), artifact_path=arts[0] if arts else None, T_cam_to_world=T_cam_to_world,
-        only_bg=args.only_bg)
+    from .clip import DeviceClip
+    artifact = _first_artifact(args.input_dir)
+    clip = None if os.environ.get("EGOPRIOR_STREAM_CLIP") == "1" else DeviceClip.load(_engine(), artifact)
+    if clip is not None:
+        # The clip is decoded once into HBM; the background cloud is built from it and stays on the GPU, and the frame
+        # loop takes its exo frames from the same tensors.  Same kernels on the same values as the two public functions
+        # below produce through their numpy returns.
+        if args.use_mean_bg:
+            bg, _ = _mean_background_cloud(clip.frames(tolerant=True), T_cam_to_world, 2, None, want_xyz64=False)
+        else:
+            clouds, _ = _accumulated_background_clouds(clip.frames(tolerant=True), T_cam_to_world, 2, want_xyz64=False)
+            if not clouds:
+                logger.warning("No valid background points found in any frame")
+            bg = _concat_clouds(clouds) if clouds else None
+        if bg is None or bg.n() == 0:
+            logger.error("No points in background point cloud. Exiting.")
+            return
+        validate_frame_range(args, len(ego_list), args.input_dir)
+        coeffs, aria_size = _lens_setup(args.fish_eye_rendering, args.online_calibration_path, (2880, 2880))
+        frames = _render_sequence(bg, None if args.only_bg else clip.frames(tolerant=False),
+                                  ego_list[args.start_frame:args.end_frame + 1], ego_intrinsic, fixed_image_size,
+                                  args.point_size, args.fish_eye_rendering, coeffs, aria_size, T_cam_to_world)
+    else:
+        if args.use_mean_bg:
+            res = build_mean_background_pointcloud(args.input_dir, T_cam_to_world)
+        else:
+            res = build_background_pointcloud(args.input_dir, T_cam_to_world)
+        bg_pts, bg_cols = res[0], res[1]
+        if len(bg_pts) == 0:
+            logger.error("No points in background point cloud. Exiting.")
+            return
+        validate_frame_range(args, len(ego_list), args.input_dir)
+        frames = project_points_to_image_sequential(
+            bg_pts, bg_cols, ego_list[args.start_frame:args.end_frame + 1], ego_intrinsic, fixed_image_size,
+            args.point_size, use_fisheye=args.fish_eye_rendering, online_calibration_path=args.online_calibration_path,
+            original_image_size=(2880, 2880), artifact_path=artifact, T_cam_to_world=T_cam_to_world,
+            only_bg=args.only_bg)
     out = write_video(Path(args.out_dir) / "ego_Prior.mp4", frames, fps=30)
     logger.info(f"Rendering complete. Saved {len(frames)} frames to {out}")
     if args.dump_frames and frames:

@@ -446,3 +446,46 @@ def test_depth_from_the_converter_output_directory(tmp_path):
     assert some[0][1] is eio.SKIPPED and np.array_equal(some[4][1], frames[4])
     with pytest.raises(FileNotFoundError):
         list(eio.read_depth_artifacts(tmp_path / "depth" / "other.zip"))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# native container decoders (csrc/libegoprior_codec.so) against the Python decoders
+# ----------------------------------------------------------------------------------------------------------------------
+def test_native_codec_is_built_and_agrees_with_the_python_decoders():
+    from egoprior import io as eio
+    assert eio.native_codec() is not None, "csrc/libegoprior_codec.so is missing: run make -C egox-egopriorrenderer_amd/csrc"
+    rng = np.random.default_rng(5)
+    for (H, W) in [(37, 53), (16, 64), (1, 1), (33, 2)]:
+        d = (rng.random((H, W)) * 7).astype(np.float16)
+        d[rng.random((H, W)) < 0.2] = np.nan
+        d[: H // 2, : W // 2] = 1.5  # runs, so that RLE and deflate have something to find
+        for comp in (0, 1, 2, 3):
+            buf = eio.encode_exr_half_z(d, compression=comp)
+            a = eio.decode_exr_half_z(buf)
+            b = eio.decode_exr_half_z(buf, native=False)
+            assert a.dtype == b.dtype == np.float16 and a.tobytes() == b.tobytes() == d.tobytes(), (H, W, comp)
+            assert eio.exr_size(buf) == (H, W)
+            out = np.empty((H, W), dtype=np.float16)
+            assert eio.decode_exr_half_z(buf, out=out) is out and out.tobytes() == d.tobytes()
+            with pytest.raises(OSError):
+                eio.decode_exr_half_z(buf[: len(buf) // 2])
+        m = (rng.integers(0, 4, (H, W)) * (rng.random((H, W)) < 0.5)).astype(np.uint8)
+        for filters in ([0], [1], [2], [3], [4], [4, 3, 2, 1, 0]):
+            png = _png_with_filters(m, filters)
+            a = eio.decode_png_gray(png)
+            b = eio.decode_png_gray(png, native=False)
+            assert a.dtype == np.uint8 and a.tobytes() == b.tobytes() == m.tobytes(), (H, W, filters)
+    with pytest.raises(ValueError):
+        eio.decode_exr_half_z(buf, out=np.empty((3, 3), dtype=np.float16))
+    # a 16-bit greyscale file is outside the native subset and still decodes
+    import struct
+    import zlib
+    v = rng.integers(0, 65536, (5, 7)).astype(">u2")
+    raw = b"".join(b"\0" + v[y].tobytes() for y in range(5))
+
+    def chunk(t, dd):
+        return struct.pack(">I", len(dd)) + t + dd + struct.pack(">I", zlib.crc32(t + dd) & 0xFFFFFFFF)
+
+    png16 = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 16, 0, 0, 0, 0))
+             + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    assert np.array_equal(eio.decode_png_gray(png16), v.astype(np.uint16))

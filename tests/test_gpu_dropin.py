@@ -5,6 +5,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import oracle as O
 
@@ -312,3 +313,83 @@ def test_cli_under_torchrun_with_rccl(clip_dir, tmp_path, mode):
     a, b = np.load(one / "ego_Prior.npy"), np.load(two / "ego_Prior.npy")
     assert a.shape == b.shape == (c["F"], 448, 448, 3) and a.any()
     assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the clip held in HBM (egoprior.clip.DeviceClip) against the streaming readers
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def exr_clip_dir(tmp_path_factory):
+    """A clip in the reference's containers (depth: zip of EXR files, masks: zip of PNG files) whose third depth member
+    is damaged, which both readers have to turn into an all-NaN frame (vipe/utils/io.py:293-305)."""
+    import zipfile
+    from egoprior import io as eio, synth
+    base = tmp_path_factory.mktemp("vipe_results_exr") / "take02"
+    F, H, W = 6, 72, 128
+    d, rgb, m = [t.numpy() for t in synth.make_frames(H, W, range(F), F)]
+    intr = synth.exo_intrinsics(H, W)
+    eio.write_synthetic_artifacts(base, "exo", d, rgb, m, intr, np.eye(4, dtype=F32), depth_as_exr_zip=True)
+    zp = base / "depth" / "exo.zip"
+    with zipfile.ZipFile(zp) as z:
+        members = {n: z.read(n) for n in z.namelist()}
+    members["00002.exr"] = members["00002.exr"][:200]
+    with zipfile.ZipFile(zp, "w", zipfile.ZIP_DEFLATED) as z:
+        for n, b in members.items():
+            z.writestr(n, b)
+    fx = synth.load_camera_fixture()
+    exo = synth.exo_w2c(fx)
+    egos = synth.ego_orbit_w2c(F, exo)
+    K_ego = [[150.0, 0, 224.0], [0, 150.0, 224.0], [0, 0, 1]]
+    meta = base.parent / "meta.json"
+    meta.write_text(json.dumps({"test_datasets": [{
+        "exo_path": "./videos/take02/exo.mp4", "camera_intrinsics": fx["cam01"]["camera_intrinsics"],
+        "camera_extrinsics": exo[:3].tolist(), "ego_intrinsics": K_ego,
+        "ego_extrinsics": [np.asarray(e)[:3].tolist() for e in egos]}]}))
+    return dict(base=base, meta=meta, F=F, H=H, W=W)
+
+
+def test_resident_clip_holds_what_the_streaming_readers_yield(exr_clip_dir):
+    from egoprior import render_vipe_pointcloud as rv
+    from egoprior.clip import DeviceClip
+    from egoprior.io import SKIPPED
+    c = exr_clip_dir
+    art = rv._first_artifact(str(c["base"]))
+    clip = DeviceClip.load(rv._engine(), art)
+    assert clip is not None and clip.n_frames == c["F"] and clip.depth.dtype == torch.float16
+    n = 0
+    for f, ((c2w, rgb, k, ct, depth, mask), (c2w2, rgb2, k2, ct2, depth2, mask2)) in enumerate(
+            zip(rv._frames(art, tolerant=False), clip.frames(tolerant=False))):
+        assert np.array_equal(c2w, c2w2) and np.array_equal(k, k2) and ct == ct2
+        assert np.array_equal(rgb, rgb2.cpu().numpy()) and np.array_equal(mask, mask2.cpu().numpy())
+        assert depth.dtype == np.float16 or f == 2
+        assert np.array_equal(np.asarray(depth, dtype=np.float32), depth2.float().cpu().numpy(), equal_nan=True)
+        assert np.isnan(np.asarray(depth, dtype=np.float32)).all() == (f == 2)
+        n += 1
+    assert n == c["F"]
+    # a rank's share: only the wanted frames are decoded and held, in clip order
+    part = DeviceClip.load(rv._engine(), art, wanted={1, 4})
+    assert part.index == [1, 4] and part.rgb.shape[0] == 2
+    items = list(part.frames(tolerant=True))
+    assert items[0][1] is SKIPPED and items[0][4] is SKIPPED
+    assert torch.equal(items[4][4], clip.depth[4]) and torch.equal(items[1][1], clip.rgb[1])
+
+
+@pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_dyn"])
+def test_cli_is_the_same_with_the_clip_resident_or_streamed(exr_clip_dir, tmp_path, mode, monkeypatch):
+    from egoprior import render_vipe_pointcloud as rv
+    c = exr_clip_dir
+    outs = []
+    for stream in ("0", "1"):
+        monkeypatch.setenv("EGOPRIOR_STREAM_CLIP", stream)
+        out_dir = tmp_path / f"out{stream}"
+        argv = ["--input_dir", str(c["base"]), "--out_dir", str(out_dir), "--meta_json_path", str(c["meta"]),
+                "--point_size", "5.0", "--start_frame", "0", "--end_frame", str(c["F"] - 1)]
+        if mode == "meanbg_fisheye_dyn":
+            argv += ["--use_mean_bg", "--fish_eye_rendering"]
+        rv.main(argv)
+        got = out_dir / "take02" / "ego_Prior.npy"
+        if not got.exists():
+            pytest.skip("mp4 written (imageio present); pixel comparison needs the lossless twin")
+        outs.append(np.load(got))
+    assert outs[0].shape == (c["F"], 448, 448, 3) and outs[0].any()
+    assert np.array_equal(outs[0], outs[1])

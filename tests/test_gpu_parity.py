@@ -355,6 +355,46 @@ def test_rasterize_clustered_depths(engine, mode, splat_variant):
     assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+@pytest.mark.parametrize("mode", ["duplicates", "spread", "front_last"])
+def test_rasterize_heavy_tiles_are_sliced(engine, mode, splat_variant):
+    """A dense cloud over a few tiles: lists far longer than 32768 entries are cut into slices that several waves
+    reduce and one of them merges, and most keys never pass the per-record thresholds once the pixel lists are full.
+    duplicates: 24 exact copies of every point (the static cloud accumulated over a clip: equal depths, order by index);
+    spread: independent depths; front_last: depths that decrease along the list, so that every new batch beats the lists
+    so far.  The fragments must be the oracle's whichever way the work is cut, and the same with slicing switched off."""
+    from egoprior import _lib, engine as eng
+    H, W = 40, 48
+    ps = 4.0
+    rng = np.random.default_rng({"duplicates": 21, "spread": 22, "front_last": 23}[mode])
+    n = 360_000
+    if mode == "duplicates":
+        base = n // 24
+        xy0 = np.stack([rng.uniform(-0.55, 0.35, base), rng.uniform(-0.3, 0.45, base)], axis=1).astype(F32)
+        z0 = rng.uniform(1.0, 4.0, base).astype(F32)
+        xy, z = np.tile(xy0, (24, 1)), np.tile(z0, 24)
+    else:
+        xy = np.stack([rng.uniform(-0.55, 0.35, n), rng.uniform(-0.3, 0.45, n)], axis=1).astype(F32)
+        z = rng.uniform(1.0, 4.0, n).astype(F32)
+        if mode == "front_last":
+            z = np.sort(z)[::-1].copy()
+    ndc = np.concatenate([xy, z[:, None]], axis=1).astype(F32)
+    cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    r = O.radius_ndc(ps, H, W)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, 20, "scatter")
+    ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+    rp = eng.make_raster_params(ps, H, W, K=20, colors_gt1=1)
+    packed = pack_ndc(ndc, cols, engine.device)
+    for slices in (1, 0):
+        _lib.set_option("slices", slices)
+        try:
+            res = engine.rasterize_composite(packed, None, rp, H, W, want_f32=True, want_fragments=True)
+        finally:
+            _lib.set_option("slices", 1)
+        assert res["status"].item() == 0
+        _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+        assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+
+
 def test_rasterize_empty_and_all_behind(engine):
     from egoprior import engine as eng
     H, W = 40, 56

@@ -39,12 +39,25 @@ with tempfile.TemporaryDirectory() as tmp:
             "--point_size", "5.0", "--start_frame", "0", "--end_frame", str(F - 1)]
     if "--fisheye" in sys.argv:
         argv += ["--fish_eye_rendering", "--use_mean_bg", "--online_calibration_path", str(tmp / "calib.jsonl")]
-    rv.main(argv[:-2] + ["--end_frame", str(F - 1)])  # warm-up: library load, first-touch allocations
-    t0 = time.time()
+    rv.main(argv)  # warm-up: library load, first-touch allocations, page-locked staging buffers
+    ref = np.load(tmp / "out" / "clip" / "ego_Prior.npy") if (tmp / "out" / "clip" / "ego_Prior.npy").exists() else None
+    best = None
+    for _ in range(3):
+        t0 = time.time()
+        rv.main(argv)
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+        print(f"main(): {dt:.3f} s for {F} frames = {F / dt:.1f} frames/s end to end", flush=True)
+    print(f"best of 3: {F / best:.1f} frames/s", flush=True)
     pr = cProfile.Profile()
     pr.enable()
     rv.main(argv)
     pr.disable()
-    dt = time.time() - t0
-    print(f"main(): {dt:.2f} s for {F} frames = {F / dt:.1f} frames/s end to end", flush=True)
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    if ref is not None and "--compare-streamed" in sys.argv:
+        import os
+        os.environ["EGOPRIOR_STREAM_CLIP"] = "1"
+        t0 = time.time()
+        rv.main(argv)
+        print(f"streamed readers: {F / (time.time() - t0):.1f} frames/s; same bits: "
+              f"{np.array_equal(ref, np.load(tmp / 'out' / 'clip' / 'ego_Prior.npy'))}", flush=True)

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 from egoprior import _lib
 
-_lib.LIB_PATH = _lib.CSRC / "libegoprior_hip_tiletimes.so"
+import os
+_lib.LIB_PATH = _lib.CSRC / os.environ.get("EGOPRIOR_DIAG_LIB", "libegoprior_hip_tiletimes.so")
 from egoprior import engine as eng, synth
 
 ps = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
@@ -40,7 +41,7 @@ c = [int(v) for v in cbuf]
 tot = max(sum(c[:5]), 1)
 print("wave cycles by stage (all waves): " + ", ".join(
     f"{n} {100 * v / tot:.1f}%" for n, v in zip(("load+filter", "sort", "sweep+append", "merge", "compositor"), c[:5]))
-    + f"; total {tot:.4g} over {c[5]} waves")
+    + f"; total {tot:.4g} over {c[5]} waves; absolute (Mcycles): " + ", ".join(f"{v / 1e6:.1f}" for v in c[:5]))
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()
 assert dbg(buf, 4 * n_tiles) == 0

@@ -189,7 +189,9 @@ int egoprior_project_points(const egoprior_camera* cam, const egoprior_point* d_
  * the largest number of tiles a disc of that radius can overlap (8 bytes per point-tile pair), so it cannot overflow
  * for that n.  Any smaller workspace is accepted too (at least egoprior_raster_workspace_bytes_entries(H, W, n, 0)):
  * the lists then hold what fits and d_status reports the rest; egoprior_count_list_entries gives the exact need of a
- * frame beforehand.  List positions are 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused
+ * frame beforehand.  About a ninth of the size is the slice area: a tile whose list exceeds 32768 entries is cut into
+ * slices that separate waves reduce to per-pixel lists (10 KiB per slice) before one of them merges the lists and
+ * shades the tile; lists and slice area share the workspace in a fixed ratio, whatever its size.  List positions are 32-bit: a call with n times that number of tiles above 2^32 - 16 is refused
  * with EGOPRIOR_E_INVALID (split the cloud).
  * --------------------------------------------------------------------------------------------------------------- */
 size_t egoprior_raster_workspace_bytes(int32_t H, int32_t W, int64_t n, float radius);
@@ -260,7 +262,8 @@ int egoprior_profile_begin(void);
  * the same bits.
  * "fill_pieces": 1 default: the tile lists are filled without global atomics where the counting pass could leave its
  * per-workgroup offsets, 0: always one reservation per run of lanes.  "bin_lds": 1 default: the tile counts are
- * aggregated per workgroup in LDS, 0: straight global atomics. */
+ * aggregated per workgroup in LDS, 0: straight global atomics.  "slices": 1 default: tiles with more than 32768 list
+ * entries are split over several waves, 0: one wave per tile always. */
 int egoprior_set_option(const char* name, int32_t value);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
                          int32_t* n_kernels);

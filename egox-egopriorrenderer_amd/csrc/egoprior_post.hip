@@ -47,7 +47,43 @@ __global__ void __launch_bounds__(256) k_white_pixels(const uint8_t* __restrict_
     }
 }
 
+// The reference's post-processing with a background image (scripts/render_vipe_pointcloud.py:873-888, 1085-1097):
+// rendered = clamp(compositor output, 0, 1); a pixel whose three channels are all below 1e-2 takes the background
+// image's pixel instead; uint8 by truncation of clip(., 0, 1) * 255; optional 90-degree clockwise rotation
+// (out[i][j] = in[H-1-j][i], out is W x H).
+__global__ void __launch_bounds__(256) k_postprocess_background(const float* __restrict__ img,
+                                                                const float* __restrict__ bg, int H, int W,
+                                                                int rotate_cw, uint8_t* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+    float c[3];
+    bool dark = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = fminf(fmaxf(img[p * 3 + k], 0.0f), 1.0f);
+        dark = dark && (c[k] < 1e-2f);
+    }
+    const size_t o = rotate_cw ? ((size_t)x * H + (size_t)(H - 1 - y)) : (size_t)p;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = dark ? bg[p * 3 + k] : c[k];
+        out[o * 3 + k] = (uint8_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f);
+    }
+}
+
 }  // namespace ep
+
+extern "C" int egoprior_postprocess_background(const float* d_image_f32, const float* d_background_f32, int32_t H,
+                                               int32_t W, int32_t rotate_cw, uint8_t* d_image_u8, void* stream) {
+    if (d_image_f32 == nullptr || d_background_f32 == nullptr || d_image_u8 == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    const int64_t n = (int64_t)H * W;
+    EP_LAUNCH("k_postprocess_background", ep::k_postprocess_background, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+              (hipStream_t)stream, d_image_f32, d_background_f32, (int)H, (int)W, (int)rotate_cw, d_image_u8);
+    return ep_host::check_launch("postprocess_background");
+}
 
 extern "C" int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32_t H, int32_t W,
                                            float threshold, int32_t grey_rule, int32_t* d_counts, uint8_t* d_masks,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "egoprior_render_frame": (C.c_int, [C.POINTER(Camera), C.POINTER(RasterParams), _vp, _i64, _vp, _vp, _vp, _i64,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "egoprior_white_pixel_counts": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "egoprior_postprocess_background": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "egoprior_set_option": (C.c_int, [C.c_char_p, _i32]),
     "egoprior_profile_begin": (C.c_int, []),
     "egoprior_profile_end": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _i32, _vp]),

@@ -340,6 +340,20 @@ class Engine:
                                                      _ptr(masks), _stream()))
         return (counts[:n], masks) if want_masks else counts[:n]
 
+    def postprocess_background(self, image_f32, background_f32, rotate_cw: bool) -> torch.Tensor:
+        """uint8 frame from the compositor's float32 output and a float32 background image in 0..1 (the reference's
+        clamp / dark-pixel / background / uint8 / rotation steps, scripts/render_vipe_pointcloud.py:873-888)."""
+        img = self.to_device(image_f32, torch.float32)
+        bg = self.to_device(background_f32, torch.float32)
+        H, W = int(img.shape[0]), int(img.shape[1])
+        if tuple(img.shape) != (H, W, 3) or tuple(bg.shape) != (H, W, 3):
+            raise ValueError("image and background must both be (H, W, 3)")
+        out = torch.empty((W, H, 3) if rotate_cw else (H, W, 3), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_postprocess_background(_ptr(img), _ptr(bg), H, W, int(bool(rotate_cw)), _ptr(out),
+                                                         _stream()))
+        return out
+
     def render_frame(self, cam: Camera, rp: RasterParams, a: DeviceCloud, b: Optional[DeviceCloud] = None,
                      want_f32: bool = False, want_fragments: bool = False, out_image: Optional[torch.Tensor] = None):
         H, W = cam.H, cam.W

@@ -345,9 +345,17 @@ def _background_u8(W, H, mode, color, noise_range, seed):
     return bg
 
 
-def _check_bg(background_mode, background_color):
-    if background_mode != "solid" or tuple(float(c) for c in background_color) != (0.0, 0.0, 0.0):
-        raise NotImplementedError("only the solid black background the reference ever passes is implemented")
+def _is_black(background_mode, background_color) -> bool:
+    return background_mode == "solid" and tuple(float(c) for c in background_color) == (0.0, 0.0, 0.0)
+
+
+def _finish(res, rotate_cw, W, H, background_mode, background_color, noise_range, seed) -> np.ndarray:
+    """The uint8 frame of a render call: the kernel's own for the black background the reference's main always passes,
+    otherwise the compositor's float32 output post-processed against the generated background image (:794-797, :873-888)."""
+    if _is_black(background_mode, background_color):
+        return res["image"].cpu().numpy()
+    bg = _background_u8(W, H, background_mode, background_color, noise_range, seed)
+    return _engine().postprocess_background(res["image_f32"], bg, rotate_cw).cpu().numpy()
 
 
 def render_points_pytorch3d(points_world, colors_world, K, T_c2w=None, T_w2c=None, W=640, H=480, point_size=2,
@@ -355,15 +363,17 @@ def render_points_pytorch3d(points_world, colors_world, K, T_c2w=None, T_w2c=Non
                             noise_range=(0, 255), seed=42, _cloud=None, _dyn=None):
     """One pinhole ego frame, uint8, rotated 90 degrees clockwise ((W,H,3)); (H,W,3) background when no point
     survives the finite / |p| < 1e6 filters."""
-    cam, rp = _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size, background_mode, background_color)
+    cam, rp = _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size)
     E = _engine()
     cloud = _cloud if _cloud is not None else _upload(points_world, colors_world)
     if cloud.n() + (_dyn.n() if _dyn is not None else 0) == 0:
         return (_background_u8(W, H, background_mode, background_color, noise_range, seed) * 255).astype(np.uint8)
-    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+    black = _is_black(background_mode, background_color)
+    res = E.render_frame(cam, rp, cloud, _dyn, want_f32=not black)
+    return _finish(res, True, W, H, background_mode, background_color, noise_range, seed)
 
 
-def _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size, background_mode="solid", background_color=(0.0, 0.0, 0.0)):
+def _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size):
     """Argument checks and camera / raster parameters of render_points_pytorch3d (same assertions, same order)."""
     if T_w2c is None:
         assert T_c2w is not None, "Provide either T_w2c or T_c2w."
@@ -373,7 +383,6 @@ def _pinhole_setup(K, T_c2w, T_w2c, W, H, point_size, background_mode="solid", b
     assert np.isfinite(R_cv).all(), "R has NaN/Inf"
     assert np.isfinite(t_cv).all(), "t has NaN/Inf"
     assert np.isfinite(np.asarray(K)).all(), "K has NaN/Inf"
-    _check_bg(background_mode, background_color)
     return _eng.pinhole_camera(R_cv, t_cv, K, H, W), _eng.make_raster_params(point_size, H, W, K=20, rotate_cw=True)
 
 
@@ -387,7 +396,6 @@ def render_points_fisheye(points_world, colors_world, T_w2c, ego_intrinsics, W=6
     R_cv, t_cv = _eng.split_w2c(T_w2c)
     assert np.isfinite(R_cv).all(), "R has NaN/Inf"
     assert np.isfinite(t_cv).all(), "t has NaN/Inf"
-    _check_bg(background_mode, background_color)
     E = _engine()
     cloud = _cloud if _cloud is not None else _upload(points_world, colors_world)
     if cloud.n() + (_dyn.n() if _dyn is not None else 0) == 0:
@@ -395,7 +403,9 @@ def render_points_fisheye(points_world, colors_world, T_w2c, ego_intrinsics, W=6
     cam, rp = _fisheye_setup(R_cv, t_cv, ego_intrinsics, W, H, point_size, radial_distortion_coeffs,
                              tangential_distortion_coeffs, thinPrism_distortion_coeffs, focal_length, principal_point,
                              original_image_size)
-    return E.render_frame(cam, rp, cloud, _dyn)["image"].cpu().numpy()
+    black = _is_black(background_mode, background_color)
+    res = E.render_frame(cam, rp, cloud, _dyn, want_f32=not black)
+    return _finish(res, False, W, H, background_mode, background_color, noise_range, seed)
 
 
 def _fisheye_setup(R_cv, t_cv, ego_intrinsics, W, H, point_size, radial_distortion_coeffs, tangential_distortion_coeffs,

@@ -219,6 +219,17 @@ int egoprior_render_frame(const egoprior_camera* cam, const egoprior_raster_para
                           void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * The renderers' post-processing with a background image that is not black (:794-797 / :947-950 build it with
+ * generate_background, :873-888 / :1085-1097 apply it): d_image_f32 is the (H,W,3) compositor output of
+ * egoprior_rasterize_composite / egoprior_render_frame, d_background_f32 an (H,W,3) float32 image in 0..1.  A pixel whose
+ * clamped channels are all below 1e-2 takes the background's pixel; the result is clipped, scaled by 255 and truncated
+ * to uint8, and rotated by 90 degrees clockwise into a (W,H,3) image when rotate_cw is set.  (With a black background
+ * this is what those two entry points write to d_image_u8 themselves.)
+ * --------------------------------------------------------------------------------------------------------------- */
+int egoprior_postprocess_background(const float* d_image_f32, const float* d_background_f32, int32_t H, int32_t W,
+                                    int32_t rotate_cw, uint8_t* d_image_u8, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Exact sizing of the tile lists (optional first call of a two-call mode; no counterpart in the reference, whose
  * pytorch3d rasterizer caps its bins and drops points instead).  Runs the projection (cam != NULL: [a | b] are world
  * points; cam == NULL: d_a holds n_a NDC records, image size H x W, no part b) and the per-tile counting pass, and

@@ -464,11 +464,13 @@ def composite(idx, dists, feats, radius: float, background=(0.0, 0.0, 0.0)) -> n
     return out
 
 
-def postprocess(img_f32: np.ndarray, rotate_cw: bool) -> np.ndarray:
+def postprocess(img_f32: np.ndarray, rotate_cw: bool, bg_img: np.ndarray = None) -> np.ndarray:
+    """scripts/render_vipe_pointcloud.py:879-888 (RGB branch): clamp, dark pixels take the background image's pixel
+    (black when bg_img is None, the only background the reference's main ever passes), uint8 by truncation, rotation."""
     rgb = np.clip(img_f32, F32(0), F32(1))
     dark = np.all(rgb < F32(1e-2), axis=2)
     rgb = rgb.copy()
-    rgb[dark] = F32(0)
+    rgb[dark] = F32(0) if bg_img is None else np.asarray(bg_img, dtype=F32)[dark]
     u8 = (np.clip(rgb, F32(0), F32(1)) * F32(255)).astype(np.uint8)
     if rotate_cw:
         u8 = np.ascontiguousarray(np.rot90(u8, k=-1))  # out[i][j] = in[H-1-j][i]

@@ -67,6 +67,44 @@ def test_python_surface_builders(clip_dir):
     assert np.array_equal(mp2, rmp2)
 
 
+@pytest.mark.parametrize("mode,color", [("uniform_noise", (0.0, 0.0, 0.0)), ("gaussian_noise", (0.0, 0.0, 0.0)),
+                                        ("solid", (0.25, 0.5, 1.0))])
+def test_render_functions_with_other_backgrounds(clip_dir, mode, color):
+    """Backgrounds other than black (never passed by the reference's main, but part of both renderers' signatures,
+    :756-757, :899-900): dark pixels take the generated background image's pixel, :873-888."""
+    from egoprior import render_vipe_pointcloud as rv
+    c = clip_dir
+    pts, cols, T = _oracle_static(c)
+    W, H, ps = 200, 120, 3.0
+    kw = dict(background_mode=mode, background_color=color, noise_range=(20, 230), seed=7)
+    bg = rv.generate_background(W, H, mode, color, (20, 230), 7) if mode != "solid" \
+        else np.full((H, W, 3), color, dtype=F32)
+    assert bg.dtype == F32 and bg.shape == (H, W, 3)
+    _, fr = O.render_points_pinhole(pts, cols, c["K_ego"], c["egos"][1], W, H, ps, return_fragments=True)
+    f32 = O.composite(fr["idx"], fr["dists"], fr["cols"], fr["radius"])
+    ref = O.postprocess(f32, True, bg_img=bg)
+    img = rv.render_points_pytorch3d(pts, cols, c["K_ego"], T_w2c=c["egos"][1], W=W, H=H, point_size=ps, **kw)
+    assert img.dtype == np.uint8 and img.shape == (W, H, 3) and np.array_equal(img, ref)
+    black = O.postprocess(f32, True)
+    assert (img != black).any() and np.array_equal(img[black.any(axis=2)], black[black.any(axis=2)])
+    # fisheye: not rotated; the GPU's own float32 composite is the input of the reference recipe
+    fxp = json.loads(c["calib"].read_text())["CameraCalibrations"][0]["Projection"]["Params"]
+    fe = dict(radial_distortion_coeffs=fxp[3:9], tangential_distortion_coeffs=fxp[9:11],
+              thinPrism_distortion_coeffs=fxp[11:15])
+    img_f = rv.render_points_fisheye(pts, cols, c["egos"][1], c["K_ego"], W=112, H=112, point_size=ps, **fe, **kw)
+    base_f = rv.render_points_fisheye(pts, cols, c["egos"][1], c["K_ego"], W=112, H=112, point_size=ps, **fe)
+    bg_f = rv.generate_background(112, 112, mode, color, (20, 230), 7) if mode != "solid" \
+        else np.full((112, 112, 3), color, dtype=F32)
+    bg_u8 = (np.clip(bg_f, 0.0, 1.0) * 255).astype(np.uint8)
+    lit = base_f.any(axis=2)
+    assert img_f.shape == (112, 112, 3) and np.array_equal(img_f[lit], base_f[lit])
+    assert np.array_equal(img_f[~lit], bg_u8[~lit])
+    # no point survives: the background image itself, un-rotated
+    out = rv.render_points_pytorch3d(np.full((5, 3), np.nan), np.zeros((5, 3), np.uint8), c["K_ego"],
+                                     T_w2c=c["egos"][0], W=W, H=H, **kw)
+    assert np.array_equal(out, (bg * 255).astype(np.uint8))
+
+
 def test_render_functions_numpy_in_numpy_out(clip_dir):
     from egoprior import render_vipe_pointcloud as rv
     c = clip_dir

@@ -217,3 +217,19 @@ def test_config_a_plumbing_on_the_cpu():
     assert img.shape == (448, 448, 3) and img.dtype == np.uint8 and img.any()
     whole = O.render_points_pinhole(pts, cols, K_ego, np.asarray(synth.ego_orbit_w2c(49, exo)[24], dtype=F32), 448, 448, 1.0)
     assert np.array_equal(whole, img)
+
+
+def test_postprocess_with_a_background_image():
+    """scripts/render_vipe_pointcloud.py:879-885: a pixel is background when all three clamped channels are below 1e-2,
+    and then takes the background image's pixel; uint8 by truncation."""
+    img = np.array([[[0.0, 0.0, 0.0], [0.009, 0.0099, 0.0], [0.5, 0.0, 0.0]],
+                    [[0.01, 0.0, 0.0], [-3.0, 0.005, 0.0], [2.0, 0.999, 0.0039]]], dtype=np.float32)
+    bg = np.full((2, 3, 3), 0.5, dtype=np.float32)
+    bg[0, 1] = (1.5, -0.2, 0.9999)
+    out = O.postprocess(img, False, bg_img=bg)
+    assert out.tolist() == [[[127, 127, 127], [255, 0, 254], [127, 0, 0]],
+                            [[2, 0, 0], [127, 127, 127], [255, 254, 0]]]
+    assert O.postprocess(img, False).tolist() == [[[0, 0, 0], [0, 0, 0], [127, 0, 0]],
+                                                  [[2, 0, 0], [0, 0, 0], [255, 254, 0]]]
+    rot = O.postprocess(img, True, bg_img=bg)
+    assert rot.shape == (3, 2, 3) and rot[0, 1].tolist() == [127, 127, 127] and rot[2, 0].tolist() == [255, 254, 0]

@@ -489,3 +489,56 @@ def test_native_codec_is_built_and_agrees_with_the_python_decoders():
     png16 = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 16, 0, 0, 0, 0))
              + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
     assert np.array_equal(eio.decode_png_gray(png16), v.astype(np.uint16))
+
+
+def test_native_inflate_agrees_with_zlib():
+    """The codec library's own inflate (a fast path in front of zlib) on streams of every block type, several window
+    sizes and flush patterns: whenever it accepts a stream its output is zlib's, and damaged or truncated streams and
+    wrong expected sizes are never accepted with other bytes than zlib would give."""
+    import ctypes as C
+    import zlib
+    from egoprior import io as eio
+    L = eio.native_codec()
+    assert L is not None
+    L.epc_inflate_exact.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32]
+    L.epc_inflate_exact.restype = C.c_int
+    rng = np.random.default_rng(77)
+
+    def make(kind, n):
+        if kind == 0:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 1:
+            return (rng.integers(0, 4, n, dtype=np.uint8) * 17).tobytes()
+        if kind == 2:
+            return np.repeat(rng.integers(0, 256, n // 50 + 1, dtype=np.uint8), 50)[:n].tobytes()
+        if kind == 3:
+            return bytes(n)
+        if kind == 4:
+            return (rng.integers(0, 256, 300, dtype=np.uint8).tobytes() * (n // 300 + 1))[:n]
+        return np.frombuffer(rng.normal(2.0, 0.5, n // 2 + 1).astype(np.float16).tobytes(), dtype=np.uint8)[:n].tobytes()
+
+    accepted = 0
+    for it in range(240):
+        n = int(rng.choice([0, 1, 2, 7, 63, 65, 257, 258, 259, 1000, 4099, 61440, 100003]))
+        raw = make(int(rng.integers(0, 6)), n)
+        strat = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, int(rng.choice([9, 12, 15])), 9, strat)
+        cut = int(rng.integers(0, n + 1))
+        comp = co.compress(raw[:cut]) + co.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_NO_FLUSH])))
+        comp += co.compress(raw[cut:]) + co.flush()
+        out = (C.c_uint8 * (n + 64))()
+        if L.epc_inflate_exact(comp, len(comp), out, n, 1) == 0:
+            accepted += 1
+            assert bytes(out[:n]) == raw, it
+        assert L.epc_inflate_exact(comp, len(comp), out, n, 0) == 0 and bytes(out[:n]) == raw  # with the zlib fallback
+        if len(comp) > 8:
+            bad = bytearray(comp)
+            bad[int(rng.integers(2, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+            if L.epc_inflate_exact(bytes(bad), len(bad), out, n, 1) == 0:
+                assert zlib.decompress(bytes(bad)) == bytes(out[:n])
+            short = comp[: int(rng.integers(0, len(comp)))]
+            assert L.epc_inflate_exact(short, len(short), out, n, 0) != 0
+            if n:
+                assert L.epc_inflate_exact(comp, len(comp), out, n - 1, 0) != 0
+            assert L.epc_inflate_exact(comp, len(comp), (C.c_uint8 * (n + 65))(), n + 1, 0) != 0
+    assert accepted >= 230  # it is there to be used, not to decline

@@ -395,6 +395,41 @@ def test_rasterize_heavy_tiles_are_sliced(engine, mode, splat_variant):
         assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_rasterize_random_geometry(engine, seed):
+    """Random image sizes (ragged last tiles), point sizes from sub-pixel to a quarter of the image, K of 1, 5 or 20,
+    and clouds that mix a uniform spread with a tight blob (every fourth seed: a blob dense enough for its tiles to be
+    sliced) and depth ties: fragments and composite against the oracle."""
+    from egoprior import engine as eng
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(9, 90)), int(rng.integers(9, 90))
+    ps = float(rng.choice([0.4, 1.0, 2.0, 3.5, 6.0, 11.0]))
+    K = int(rng.choice([1, 5, 20]))
+    n_uniform = int(rng.integers(100, 20000))
+    n_blob = 150_000 if seed % 4 == 3 else int(rng.integers(0, 30000))
+    half_x, half_y = max(W / H, 1.0), max(H / W, 1.0)
+    xy_u = np.stack([rng.uniform(-1.1 * half_x, 1.1 * half_x, n_uniform),
+                     rng.uniform(-1.1 * half_y, 1.1 * half_y, n_uniform)], axis=1)
+    c = np.array([rng.uniform(-0.6, 0.6) * half_x, rng.uniform(-0.6, 0.6) * half_y])
+    xy_b = c + rng.normal(0.0, 0.08, (n_blob, 2))
+    xy = np.concatenate([xy_u, xy_b]).astype(F32)
+    z = rng.uniform(0.5, 9.0, xy.shape[0]).astype(F32)
+    z[rng.random(z.shape[0]) < 0.05] = F32(2.5)           # ties, resolved by index
+    z[rng.random(z.shape[0]) < 0.01] = F32(-1.0)          # behind the camera
+    order = rng.permutation(xy.shape[0])
+    ndc = np.concatenate([xy, z[:, None]], axis=1).astype(F32)[order]
+    cols = rng.integers(0, 256, (ndc.shape[0], 3), dtype=np.uint8)
+    r = O.radius_ndc(ps, H, W)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, K, "scatter")
+    rp = eng.make_raster_params(ps, H, W, K=K, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, H, W, want_f32=True,
+                                     want_fragments=True)
+    assert res["status"].item() == 0
+    _check_fragments(res, ref_idx, ref_z, ref_d, K)
+    ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+    assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+
+
 def test_rasterize_empty_and_all_behind(engine):
     from egoprior import engine as eng
     H, W = 40, 56

@@ -249,7 +249,8 @@ __host__ __device__ __forceinline__ uint32_t slice_span(uint32_t count, uint32_t
     return (((count + ns - 1u) / ns) + 63u) & ~63u;
 }
 
-__global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__ tile_count,
+template <int NT>
+__global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor,
                                                     uint32_t* __restrict__ tile_order, int n_tiles, uint32_t capacity,
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
     uint32_t want = 0;  // slots the heavy tiles among this thread's tiles would take
-    for (int base = 0; base < n_tiles; base += 1024 * PT) {
+    for (int base = 0; base < n_tiles; base += NT * PT) {
         const int t0 = base + tid * PT;
         uint32_t v[PT];
         uint32_t sum = 0;
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
             run += v[k];
         }
         __syncthreads();
-        if (tid == 1023) carry_s = run;
+        if (tid == NT - 1) carry_s = run;
         __syncthreads();
     }
     if (tid == 0) {
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
         ohist[tid] = woff + incl - c;
     }
     __syncthreads();
-    for (int t = tid; t < n_tiles; t += 1024) {
+    for (int t = tid; t < n_tiles; t += NT) {
         const uint32_t v = tile_count[t];
         tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
     }
@@ -341,12 +342,12 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
     const bool slicing = want_all != 0u && want_all <= sp.max_slots;  // all or nothing: the slots are handed out by a scan
     if (tid == 0) *sp.total = slicing ? want_all : 0u;
     if (!slicing) return;  // (the per-tile slot words are only read when the total says that there are slices)
-    for (int t = tid; t < n_tiles; t += 1024) sp.slot_base[t] = EP_NO_SLOT;
+    for (int t = tid; t < n_tiles; t += NT) sp.slot_base[t] = EP_NO_SLOT;
     // slots of the sliced tiles: an exclusive scan of their slice counts, in tile order
     __syncthreads();
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n_tiles; base += 1024 * PT) {
+    for (int base = 0; base < n_tiles; base += NT * PT) {
         const int t0 = base + tid * PT;
         uint32_t v[PT];
         uint32_t sum = 0;
@@ -377,7 +378,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t* __restrict__
             run += v[k];
         }
         __syncthreads();
-        if (tid == 1023) carry_s = run;
+        if (tid == NT - 1) carry_s = run;
         __syncthreads();
     }
 }
@@ -1514,7 +1515,7 @@ int check_list_size(const ep::RasterGeom& g, int64_t n) {
 // The tuning switches a call works with, read once when the call starts (egoprior_set_option may change them from
 // another thread at any time; a call in progress keeps the values it started with).
 struct Tuning {
-    int splat_variant, fill_pieces, bin_lds, slices;
+    int splat_variant, fill_pieces, bin_lds, slices, scan_threads;
 };
 Tuning read_tuning() {
     Tuning t;
@@ -1522,6 +1523,7 @@ Tuning read_tuning() {
     t.fill_pieces = ep_host::option("fill_pieces");
     t.bin_lds = ep_host::option("bin_lds");
     t.slices = ep_host::option("slices");
+    t.scan_threads = ep_host::option("scan_threads");
     return t;
 }
 
@@ -1709,8 +1711,14 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                            int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
                            const RasterWs& w, const Tuning& tn, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
-    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
-              w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
+    // 1024 threads are 3 us faster on an idle GPU; 256 (one wave per SIMD, 62 VGPRs) find room on a CU whose SIMDs are full
+    // of splat waves of the frames in flight, which matters once those run for milliseconds (option "scan_threads")
+    if (tn.scan_threads == 256)
+        EP_LAUNCH("k_tile_scan", ep::k_tile_scan<256>, dim3(1), dim3(256), 0, s, w.tile_count, w.tile_start,
+                  w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
+    else
+        EP_LAUNCH("k_tile_scan", ep::k_tile_scan<1024>, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start,
+                  w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
     const bool lds = tn.bin_lds != 0 && lds_agg_possible(n_tiles, n);
     if (lds && w.pieces != nullptr)
         EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
@@ -1896,7 +1904,7 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
     if (!carve_raster_ws(d_workspace, workspace_bytes, n_tiles, n, tn, w))
         return ep_host::fail(EGOPRIOR_E_WORKSPACE, "workspace too small (egoprior_raster_workspace_bytes_entries(H, W, n, 0))");
     if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, nullptr, w, tn, s)) return e;
-    EP_LAUNCH("k_tile_scan", ep::k_tile_scan, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
+    EP_LAUNCH("k_tile_scan", ep::k_tile_scan<1024>, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr,
               ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
     EP_LAUNCH("k_copy_total", k_copy_total, dim3(1), dim3(64), 0, s, w.tile_start + n_tiles, d_entries);

@@ -122,6 +122,12 @@ def lib():
         if L.egoprior_abi_version() != ABI_VERSION:
             raise ImportError("libegoprior_hip.so ABI version mismatch")
         _LIB = L
+        # EGOPRIOR_OPTIONS="name=value,name=value": tuning switches (egoprior_set_option) for programs that have no flag
+        # for them, applied once when the library is loaded
+        for item in filter(None, os.environ.get("EGOPRIOR_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if L.egoprior_set_option(name.strip().encode(), int(value)) != 0:
+                raise ValueError(f"EGOPRIOR_OPTIONS: unknown option {name.strip()!r}")
     return _LIB
 
 

@@ -85,7 +85,7 @@ Opt g_opts[] = {
     {"fill_pieces", 1},    // 1: fill pass without global atomics where possible (k_tile_fill_pieces), 0: always k_tile_fill
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
     {"slices", 1},         // 1: tiles with very long lists are split over several waves, 0: one wave per tile always
-    {"scan_threads", 1024},  // workgroup size of the tile scan: 1024 or 256
+    {"scan_threads", 256},  // workgroup size of the tile scan: 256 or 1024
 };
 }  // namespace
 

@@ -144,8 +144,9 @@ __device__ __forceinline__ int64_t live_count(const int32_t* d_n, int64_t cap) {
 // records (b unused) and nothing is written to `out`.  LDS_AGG: the workgroup first counts into an LDS histogram of
 // all tiles and then adds the non-zero entries to global memory: consecutive points of an exo frame land on the same
 // few tiles, so this replaces thousands of same-address global atomics by a handful per workgroup.
+// (Eight waves per SIMD = at most 64 VGPRs: a workgroup then fits next to three splat waves per SIMD, which leave 65.)
 template <bool PROJECT, bool LDS_AGG>
-__global__ void __launch_bounds__(256) k_project_count(egoprior_camera cam, RasterGeom g,
+__global__ void __launch_bounds__(256, 8) k_project_count(egoprior_camera cam, RasterGeom g,
                                                        const egoprior_point* __restrict__ a, int64_t cap_a,
                                                        const int32_t* __restrict__ d_n_a,
                                                        const egoprior_point* __restrict__ b, int64_t cap_b,
@@ -1711,9 +1712,9 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                            int64_t n, const int32_t* d_n, const int32_t* d_flags_a, const int32_t* d_flags_b,
                            const RasterWs& w, const Tuning& tn, ep::SplatOut out, int32_t* d_status, hipStream_t s) {
     const int n_tiles = g.tiles_x * g.tiles_y;
-    // 1024 threads are 3 us faster on an idle GPU; 256 (one wave per SIMD, 62 VGPRs) find room on a CU whose SIMDs are full
-    // of splat waves of the frames in flight, which matters once those run for milliseconds (option "scan_threads")
-    if (tn.scan_threads == 256)
+    // 256 threads (one wave per SIMD, 62 VGPRs) find room on a compute unit whose SIMDs are full of the splat waves of the
+    // frames in flight; 1024 threads are 3 us faster on an idle GPU (option "scan_threads")
+    if (tn.scan_threads != 1024)
         EP_LAUNCH("k_tile_scan", ep::k_tile_scan<256>, dim3(1), dim3(256), 0, s, w.tile_count, w.tile_start,
                   w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
     else

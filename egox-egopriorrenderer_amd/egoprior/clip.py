@@ -8,10 +8,11 @@ page-locked staging buffers, which a copy stream moves into three resident tenso
 device tensors, to both the cloud builder and the frame loop.  A 1080p frame is 12.4 MB (float16 depth, RGB, mask): a
 thousand-frame clip is 12.4 GB of the 288 GB of HBM.
 
-Only containers that can be read frame by frame in any order take this path (depth: zip of EXR files or the .npy twin;
-masks: zip of PNG files or the .npy twin; RGB: the .npy twin); load() returns None for anything else (an mp4, which ffmpeg
-decodes in order; EXR files when the OpenEXR library is importable and therefore in charge; per-frame depth arrays) and the
-caller streams the clip through egoprior.io's iterators instead.
+Depth (zip of EXR files or the .npy twin) and masks (zip of PNG files or the .npy twin) are read frame by frame in any
+order by the worker threads; RGB comes from the .npy twin the same way, or from the mp4, which ffmpeg has to decode in
+order: one more thread walks the video reader and uploads frame after frame while the workers decode depth and masks.
+load() returns None for what is left (EXR files when the OpenEXR library is importable and therefore in charge; per-frame
+depth arrays) and the caller streams the clip through egoprior.io's iterators instead.
 """
 from __future__ import annotations
 
@@ -61,6 +62,7 @@ class _ZipMembers:
 class _Source:
     """One stream of per-frame images: n frames of `shape` and `dtype`, and fill(i, out) that decodes frame i into the
     C-contiguous host array `out`."""
+    sequential = False
     n: int
     shape: tuple
     dtype: np.dtype
@@ -80,6 +82,32 @@ class _ArraySource(_Source):
 
     def fill(self, i, out):
         np.copyto(out, self.arr[i], casting="unsafe")
+
+
+class _VideoSource(_Source):
+    """rgb/<name>.mp4 through egoprior.io.read_rgb_artifacts (imageio + ffmpeg; without imageio that reader takes the
+    .npy twin): frames arrive in order only.  n is unknown until the stream ends."""
+    sequential = True
+    dtype = np.dtype(np.uint8)
+
+    def __init__(self, path: Path):
+        self.path = Path(path)
+        self._it = _io.read_rgb_artifacts(self.path)
+        self._first = next(self._it, None)
+        self.n = None
+        self.shape = tuple(self._first[1].shape) if self._first is not None else (0, 0, 3)
+
+    def frames(self):
+        """(index, frame) in order, each frame once."""
+        if self._first is not None:
+            yield self._first
+            self._first = None
+        yield from self._it
+
+    def close(self):
+        close = getattr(self._it, "close", None)
+        if close is not None:
+            close()
 
 
 class _ExrZipSource(_Source):
@@ -196,10 +224,11 @@ class DeviceClip:
         rgb_path = Path(artifact.rgb_path)
         tw = rgb_path if rgb_path.suffix == ".npy" else rgb_path.with_suffix(".npy")
         if rgb_path.exists() and rgb_path.suffix != ".npy":
-            return None  # a video has to be decoded in order by ffmpeg: streamed
-        if not tw.exists():
+            rgb_src = _VideoSource(rgb_path)
+        elif tw.exists():
+            rgb_src = _ArraySource(tw, np.uint8)
+        else:
             raise FileNotFoundError(str(rgb_path))
-        rgb_src = _ArraySource(tw, np.uint8)
         srcs = [rgb_src]
         try:
             try:
@@ -215,7 +244,7 @@ class DeviceClip:
             except FileNotFoundError:
                 mask_src, clip.mask_missing = None, True
             # the reference zips the readers: the shortest one ends the clip
-            n = min([len(clip.poses), len(clip.intr), len(clip.types)] + [s.n for s in srcs])
+            n = min([len(clip.poses), len(clip.intr), len(clip.types)] + [s.n for s in srcs if s.n is not None])
             clip.n_frames = n
             if n == 0:
                 return clip
@@ -237,7 +266,11 @@ class DeviceClip:
             if mask_src is not None:
                 clip.mask = torch.empty((m, H, W), dtype=torch.uint8, device=dev)
             if m:
-                _fill(clip, rgb_src, depth_src, mask_src, workers)
+                got = _fill(clip, rgb_src, depth_src, mask_src, workers)
+                if got < n:  # the video ended before the other readers: it ends the clip, as in the reference's zip(...)
+                    clip.n_frames = got
+                    clip.index = [f for f in clip.index if f < got]
+                    clip._pos = {f: k for k, f in enumerate(clip.index)}
             return clip
         finally:
             for s in srcs:
@@ -267,13 +300,44 @@ class _Staging:
             return have[:count]
 
 
-def _fill(clip: DeviceClip, rgb_src, depth_src, mask_src, workers: Optional[int]) -> None:
+def _feed_video(clip: DeviceClip, rgb_src, slots, result) -> None:
+    """Walks the video in order and uploads the frames the clip holds; result[0] = number of frames the video had (up to
+    the clip's length), result[1] = an exception, if one ended the walk."""
+    try:
+        stream = torch.cuda.Stream(device=clip.rgb.device)
+        got, k = 0, 0
+        for f, frame in rgb_src.frames():
+            if f >= clip.n_frames:
+                break
+            got = f + 1
+            pos = clip._pos.get(f)
+            if pos is None or frame is _io.SKIPPED:
+                continue
+            s = slots[k & 1]
+            k += 1
+            np.copyto(s.rgb_np, frame)
+            with torch.cuda.stream(stream):
+                clip.rgb[pos].copy_(s.rgb, non_blocking=True)
+            stream.synchronize()
+        result[0] = got
+    except BaseException as e:  # handed to the caller's thread
+        result[1] = e
+
+
+def _fill(clip: DeviceClip, rgb_src, depth_src, mask_src, workers: Optional[int]) -> int:
+    """Decodes and uploads every frame the clip holds; returns the number of frames the clip turned out to have (less
+    than clip.n_frames only when an RGB video ends early)."""
     workers = workers or max(1, min(16, (os.cpu_count() or 2) - 1))
     m = len(clip.index)
     workers = min(workers, m)
     H, W = rgb_src.shape[:2]
     key = (H, W, None if clip.depth is None else clip.depth.dtype, clip.mask is not None)
-    slots = _Staging.take(key, workers + 2)
+    slots = _Staging.take(key, workers + 4)
+    video, video_result = None, [clip.n_frames, None]
+    if rgb_src.sequential:  # the last two slots' colour buffers belong to the thread that walks the video
+        video = threading.Thread(target=_feed_video, args=(clip, rgb_src, slots[-2:], video_result), daemon=True)
+        video.start()
+    slots = slots[:-2]
     free = queue.SimpleQueue()
     for s in slots:
         free.put(s)
@@ -282,7 +346,8 @@ def _fill(clip: DeviceClip, rgb_src, depth_src, mask_src, workers: Optional[int]
         f = clip.index[k]
         s = free.get()
         try:
-            rgb_src.fill(f, s.rgb_np)
+            if not rgb_src.sequential:
+                rgb_src.fill(f, s.rgb_np)
             if depth_src is not None:
                 depth_src.fill(f, s.depth_np)
             if mask_src is not None:
@@ -299,7 +364,8 @@ def _fill(clip: DeviceClip, rgb_src, depth_src, mask_src, workers: Optional[int]
             for fut in as_completed(futs):
                 k, s = fut.result()
                 with torch.cuda.stream(copy_stream):
-                    clip.rgb[k].copy_(s.rgb, non_blocking=True)
+                    if not rgb_src.sequential:
+                        clip.rgb[k].copy_(s.rgb, non_blocking=True)
                     if clip.depth is not None:
                         clip.depth[k].copy_(s.depth, non_blocking=True)
                     if clip.mask is not None:
@@ -314,3 +380,8 @@ def _fill(clip: DeviceClip, rgb_src, depth_src, mask_src, workers: Optional[int]
                 free.put(slots[0])
             raise
     torch.cuda.current_stream(clip.rgb.device).wait_stream(copy_stream)
+    if video is not None:
+        video.join()  # its uploads are complete: every one of them was followed by a synchronisation of its stream
+        if video_result[1] is not None:
+            raise video_result[1]
+    return video_result[0]

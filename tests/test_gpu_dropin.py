@@ -431,3 +431,36 @@ def test_cli_is_the_same_with_the_clip_resident_or_streamed(exr_clip_dir, tmp_pa
         outs.append(np.load(got))
     assert outs[0].shape == (c["F"], 448, 448, 3) and outs[0].any()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_resident_clip_with_rgb_that_only_comes_in_order(exr_clip_dir, tmp_path):
+    """An rgb/<name>.mp4 can only be decoded front to back: the clip loader walks it on a thread of its own while the
+    workers decode depth and masks.  Without imageio the video reader serves the .npy twin next to the (here empty)
+    mp4, which exercises the same in-order path; a video shorter than the other containers ends the clip."""
+    import shutil
+    try:
+        import imageio  # noqa: F401
+        pytest.skip("imageio present: the empty stand-in mp4 of this test would be handed to ffmpeg")
+    except ImportError:
+        pass
+    from egoprior import render_vipe_pointcloud as rv
+    from egoprior.clip import DeviceClip
+    c = exr_clip_dir
+    base = tmp_path / "take02"
+    shutil.copytree(c["base"], base)
+    (base / "rgb" / "exo.mp4").write_bytes(b"")
+    art = rv._first_artifact(str(base))
+    assert art.rgb_path.exists()
+    ref = DeviceClip.load(rv._engine(), rv._first_artifact(str(c["base"])))
+    clip = DeviceClip.load(rv._engine(), art)
+    assert clip is not None and clip.n_frames == c["F"]
+    assert torch.equal(clip.rgb, ref.rgb) and torch.equal(clip.mask, ref.mask)
+    assert torch.equal(clip.depth.view(torch.int16), ref.depth.view(torch.int16))
+    part = DeviceClip.load(rv._engine(), art, wanted={0, 3})
+    assert part.index == [0, 3] and torch.equal(part.rgb[1], ref.rgb[3])
+    # a shorter video ends the clip
+    rgb = np.load(base / "rgb" / "exo.npy")
+    np.save(base / "rgb" / "exo.npy", rgb[:4])
+    short = DeviceClip.load(rv._engine(), art)
+    assert short.n_frames == 4 and len(list(short.frames(tolerant=False))) == 4
+    assert torch.equal(short.rgb[:4], ref.rgb[:4])

@@ -154,9 +154,11 @@ def main_distributed(argv=None):
     # this rank decodes the colour images, depth maps and masks of its own frames only (plus frame 0, whose size,
     # intrinsics and camera type every rank needs)
     need = set(mine) | {slot for slot in my_slots if slot < n_frames} | {0}
-    frames = []  # (c2w, rgb, intr, type, depth, mask) per frame; rgb / depth / mask = None or io.SKIPPED for other ranks' frames
-    for i, item in enumerate(rv._frames(artifact, tolerant=True, wanted=need)):
-        frames.append(item)
+    # (c2w, rgb, intr, type, depth, mask) per frame; rgb / depth / mask = None or io.SKIPPED for other ranks' frames.  The
+    # rank's share of the clip is decoded once into HBM where the containers allow it (egoprior.clip), else streamed.
+    from .clip import DeviceClip
+    clip = None if os.environ.get("EGOPRIOR_STREAM_CLIP") == "1" else DeviceClip.load(E, artifact, wanted=need)
+    frames = list(clip.frames(tolerant=True) if clip is not None else rv._frames(artifact, tolerant=True, wanted=need))
     n_frames = len(frames)
     s = 2
     # ---- static cloud ---------------------------------------------------------------------------------------------

@@ -810,12 +810,14 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
     constexpr int PER = NB / 64;  // buckets per lane
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
-    // The bucket counters are dead once a chunk is sorted and the slot lists are dead once it is merged, so the two share
-    // storage.
-    constexpr int AUXB = (NB * 4 > (EP_K + 1) * 64 * 2) ? NB * 4 : (EP_K + 1) * 64 * 2;  // K slot rows + a spare one
+    // The bucket counters are dead once a chunk is sorted, the hit masks (one 64-bit word per pixel and block of 64
+    // records) are dead once it is merged and the threshold tables are only read while the next chunk is gathered, so the
+    // three share storage.
+    constexpr int AUX0 = (NB * 4 > C * 8) ? NB * 4 : C * 8;
+    constexpr int AUXB = AUX0 > 2 * 64 * 8 + 16 * 8 ? AUX0 : 2 * 64 * 8 + 16 * 8;
     __shared__ __align__(16) unsigned char aux[AUXB];
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
-    uint16_t(*const slots)[64] = reinterpret_cast<uint16_t(*)[64]>(aux);
+    u64(*const masks)[64] = reinterpret_cast<u64(*)[64]>(aux);
 
     // The first sp.max_slots workgroups of the launch take the slices of the heavy tiles (the slots in use come first, the
     // others leave at once); the rest take one tile each, longest list first, and leave the sliced tiles alone.
@@ -1238,6 +1240,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
         m_sweep = (int)uniform_u32((uint32_t)m_sweep);
+        int n_blocks = 0;  // blocks of 64 records that the sweep has offered to the pixels
         for (int j0 = 0; j0 < m_sweep; j0 += 64) {
             const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
             if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
@@ -1310,46 +1313,48 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     hm_hi &= (1u << (nb - 32)) - 1u;
                 }
             }
-            // Every lane appends its own hits, lowest record first, two per trip: `take` of them fit below K, and a
-            // write that has no hit left to store goes to the spare row past the K real ones.
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint32_t hm = half == 0 ? hm_lo : hm_hi;
-                const int take = min((int)__popc(hm), (int)(K - cnt));  // K - cnt >= 0
-                uint16_t* row = &slots[cnt][lane];
-                uint16_t* const spare = &slots[EP_K][lane];
-                const uint32_t jb = (uint32_t)(j0 + 32 * half);
-                cnt += take;
-                for (int i = 0; __ballot(i < take) != 0ull; i += 2) {
-                    const uint32_t t1 = (uint32_t)__builtin_ctz(hm | 0x80000000u);
-                    hm &= hm - 1u;
-                    const uint32_t t2 = (uint32_t)__builtin_ctz(hm | 0x80000000u);
-                    hm &= hm - 1u;
-                    *((i < take) ? row : spare) = (uint16_t)(jb + t1);
-                    *((i + 1 < take) ? row + 64 : spare) = (uint16_t)(jb + t2);
-                    row += 128;
-                }
-            }
+            // The pixel's hits of this block stay a bit mask: its first K hits overall are its winners, and the merge stage
+            // below walks the masks for them (extracting them here, hit by hit with every lane waiting for the one with the
+            // most hits, was a third of the kernel's instructions).
+            const u64 hm = ((u64)hm_hi << 32) | (u64)hm_lo;
+            masks[n_blocks][lane] = hm;
+            cnt = min(cnt + (int)__popcll(hm), K);
+            ++n_blocks;
         }
         __syncthreads();
         EP_STAGE(2)
-        EP_PROBE(3, (uint32_t)cnt + slots[0][lane])
+        EP_PROBE(3, (uint32_t)cnt + (uint32_t)masks[0][lane])
 
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
-        const int won = inside ? cnt : 0;
+        const int won = inside ? cnt : 0;  // at most K, and never more than the lane's hits in the masks
+        // positions in S of the lane's winners, in ascending key order: the first `won` set bits of its masks
+        uint32_t widx[EP_K];
+        {
+            int eb = 0;
+            u64 word = (n_blocks > 0) ? masks[0][lane] : 0ull;
+#pragma unroll
+            for (int p = 0; p < EP_K; ++p) {
+                widx[p] = 0u;
+                if (p < won) {
+                    while (word == 0ull) word = masks[++eb][lane];  // ends: the lane has more than p hits in all
+                    widx[p] = (uint32_t)(eb * 64 + __builtin_ctzll(word));
+                    word &= word - 1ull;
+                }
+            }
+        }
         if (chunk_no == 0) {
 #pragma unroll
             for (int k = 0; k < EP_K; ++k) {
-                if (k < won) kl[EP_K - 1 - k] = lds_key(&S[slots[k][lane]]);
+                if (k < won) kl[EP_K - 1 - k] = lds_key(&S[widx[k]]);
             }
         } else if (__ballot(won > 0) != 0ull) {
             // list[p] = min(list[p], B[p]), B = this chunk's winners in ascending order: the EP_K smallest keys of both,
-            // rising then falling; slots past `won` hold stale bits: the clamp keeps the read inside S, the value is dropped
+            // rising then falling
 #pragma unroll
             for (int p0 = 0; p0 < EP_K; p0 += 10) {  // ten at a time: twenty pending reads would not fit the registers
 #pragma unroll
                 for (int p = p0; p < p0 + 10; ++p) {
-                    const u64 w = lds_key(&S[min((int)slots[p][lane], C - 1)]);
+                    const u64 w = lds_key(&S[widx[p]]);
                     const u64 kb = (p < won) ? w : ~0ull, ka = kl[p];
                     kl[p] = kb < ka ? kb : ka;
                 }
@@ -1405,7 +1410,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         EP_STAGE(3)
     }
 #ifdef EP_TILE_TIMES
-    if (STOP != 0) {
+    if (STOP >= 1 && STOP <= 4) {
         if (STOP == 4 && (uint32_t)(kl[0] ^ kl[19]) == 0x12345u && out.image_u8 != nullptr) out.image_u8[0] = 1;
         return;
     }

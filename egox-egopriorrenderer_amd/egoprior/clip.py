@@ -259,12 +259,15 @@ class DeviceClip:
             if m * per_frame > cls.BUDGET_BYTES:
                 return None
             dev = engine.device
-            clip.rgb = torch.empty((m, H, W, 3), dtype=torch.uint8, device=dev)
-            if depth_src is not None:
-                clip.depth = torch.empty((m, H, W), device=dev,
-                                         dtype=torch.float16 if depth_src.dtype == np.float16 else torch.float32)
-            if mask_src is not None:
-                clip.mask = torch.empty((m, H, W), dtype=torch.uint8, device=dev)
+            try:
+                clip.rgb = torch.empty((m, H, W, 3), dtype=torch.uint8, device=dev)
+                if depth_src is not None:
+                    clip.depth = torch.empty((m, H, W), device=dev,
+                                             dtype=torch.float16 if depth_src.dtype == np.float16 else torch.float32)
+                if mask_src is not None:
+                    clip.mask = torch.empty((m, H, W), dtype=torch.uint8, device=dev)
+            except torch.cuda.OutOfMemoryError:
+                return None  # the card is shared and too full: stream the clip instead
             if m:
                 got = _fill(clip, rgb_src, depth_src, mask_src, workers)
                 if got < n:  # the video ended before the other readers: it ends the clip, as in the reference's zip(...)

@@ -1253,18 +1253,24 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 // wave-wide compare result is that pixel's hit mask as it stands and is dropped into its lane.
                 const float2v rxy = *reinterpret_cast<const float2v*>(&S[j0 + lane].z);
                 u64 a = act;
-                while (a != 0ull) {
+                while (a != 0ull) {  // two pixels per trip: two independent chains of scalar and vector work
                     const int p = __builtin_ctzll(a);
                     a &= a - 1ull;
-                    float2v pp;
+                    const int p2 = (a != 0ull) ? __builtin_ctzll(a) : p;  // an odd count visits the last pixel twice
+                    a &= a - 1ull;
+                    float2v pp, pq;
                     pp.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), p));
                     pp.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), p));
-                    const float2v dxy = rxy - pp;
-                    const float2v q = dxy * dxy;
-                    const float d2 = q.x + q.y;
-                    const u64 hit = __ballot(d2 < r2);
+                    pq.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), p2));
+                    pq.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), p2));
+                    const float2v dxy = rxy - pp, exy = rxy - pq;
+                    const float2v q = dxy * dxy, q2 = exy * exy;
+                    const float d2 = q.x + q.y, e2 = q2.x + q2.y;
+                    const u64 hit = __ballot(d2 < r2), hit2 = __ballot(e2 < r2);
                     hm_lo = (lane == p) ? (uint32_t)hit : hm_lo;
                     hm_hi = (lane == p) ? (uint32_t)(hit >> 32) : hm_hi;
+                    hm_lo = (lane == p2) ? (uint32_t)hit2 : hm_lo;
+                    hm_hi = (lane == p2) ? (uint32_t)(hit2 >> 32) : hm_hi;
                 }
             } else {
                 // Sixteen records at a time sit one per lane in every row of 16 lanes; a record's coordinates reach the

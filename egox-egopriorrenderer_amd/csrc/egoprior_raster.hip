@@ -817,7 +817,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     constexpr int AUXB = AUX0 > 2 * 64 * 8 + 16 * 8 ? AUX0 : 2 * 64 * 8 + 16 * 8;
     __shared__ __align__(16) unsigned char aux[AUXB];
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
-    u64(*const masks)[64] = reinterpret_cast<u64(*)[64]>(aux);
+    uint32_t(*const masks)[64] = reinterpret_cast<uint32_t(*)[64]>(aux);  // row 2 b + h: records 32 h .. 32 h + 31 of block b
 
     // The first sp.max_slots workgroups of the launch take the slices of the heavy tiles (the slots in use come first, the
     // others leave at once); the rest take one tile each, longest list first, and leave the sliced tiles alone.
@@ -1322,29 +1322,29 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             // The pixel's hits of this block stay a bit mask: its first K hits overall are its winners, and the merge stage
             // below walks the masks for them (extracting them here, hit by hit with every lane waiting for the one with the
             // most hits, was a third of the kernel's instructions).
-            const u64 hm = ((u64)hm_hi << 32) | (u64)hm_lo;
-            masks[n_blocks][lane] = hm;
-            cnt = min(cnt + (int)__popcll(hm), K);
+            masks[2 * n_blocks][lane] = hm_lo;
+            masks[2 * n_blocks + 1][lane] = hm_hi;
+            cnt = min(cnt + (int)(__popc(hm_lo) + __popc(hm_hi)), K);
             ++n_blocks;
         }
         __syncthreads();
         EP_STAGE(2)
-        EP_PROBE(3, (uint32_t)cnt + (uint32_t)masks[0][lane])
+        EP_PROBE(3, (uint32_t)cnt + masks[0][lane])
 
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
         const int won = inside ? cnt : 0;  // at most K, and never more than the lane's hits in the masks
         // positions in S of the lane's winners, in ascending key order: the first `won` set bits of its masks
         uint32_t widx[EP_K];
         {
-            int eb = 0;
-            u64 word = (n_blocks > 0) ? masks[0][lane] : 0ull;
+            int row = 0;  // 32 records per mask word
+            uint32_t word = (n_blocks > 0) ? masks[0][lane] : 0u;
 #pragma unroll
             for (int p = 0; p < EP_K; ++p) {
                 widx[p] = 0u;
                 if (p < won) {
-                    while (word == 0ull) word = masks[++eb][lane];  // ends: the lane has more than p hits in all
-                    widx[p] = (uint32_t)(eb * 64 + __builtin_ctzll(word));
-                    word &= word - 1ull;
+                    while (word == 0u) word = masks[++row][lane];  // ends: the lane has more than p hits in all
+                    widx[p] = (uint32_t)(row * 32 + __builtin_ctz(word));
+                    word &= word - 1u;
                 }
             }
         }

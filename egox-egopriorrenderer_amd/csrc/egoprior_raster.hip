@@ -486,7 +486,7 @@ typedef unsigned long long u64;
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
-// ... and the cycles all waves spent in each stage: load + filter, sort, sweep + append, merge, compositor
+// ... and the cycles all waves spent in each stage: gather, sort, sweep, extraction + merge, compositor
 __device__ unsigned long long g_stage_cycles[8];
 #define EP_STAGE(i_)                                                 \
     {                                                                \
@@ -754,10 +754,12 @@ constexpr int next_pow2(int v) {
 
 // Production variant.  One wave owns one 8x8 tile and works through the tile's point list in chunks of C list
 // entries (C/64 per lane, held in registers while the chunk is organised):
-//   load    : C/64 independent, fully coalesced 8-byte entry loads per lane (point index and depth bits); entries whose
-//             key cannot beat the largest K-th key of the tile's pixels (T) are dropped, the NDC x, y of the others are
-//             gathered from the point records, and discs that overlap the tile's rectangle without reaching any of its
-//             pixel centres are dropped too
+//   gather  : batches of C/64 independent, fully coalesced 8-byte entry loads per lane (point index and depth bits);
+//             entries whose key cannot beat the largest K-th key of the tile's pixels (T) are dropped, the NDC x, y of the
+//             others are gathered from the point records, discs that overlap the tile's rectangle without reaching any of
+//             its pixel centres are dropped too, and so are (from the third chunk on) keys that cannot beat the K-th
+//             key of any pixel row / column band their disc reaches; survivors are compacted into LDS until the chunk
+//             is full or the list ends (a batch that ends the list or fills the chunk is used straight from registers)
 //   sort    : a monotone two-level bucket map sends the keys to LDS in O(n).  Level 1 cuts the chunk's key range
 //             into NB equal ranges and histograms them; a range holding c records is cut again into 2^floor(log2 c)
 //             sub-ranges, so buckets hold a record or two unless depths repeat.  After the scatter every record ranks
@@ -768,17 +770,19 @@ constexpr int next_pow2(int v) {
 //             sixteen records at a time sit one per lane in every row of 16 lanes and reach the row's pixels as DPP row
 //             broadcasts, one hit bit per record is shifted into the pixel's mask; with few open pixels the roles swap:
 //             each lane holds one record, the open pixels' coordinates come from v_readlane and a ballot is the
-//             pixel's mask.  Hits are appended to the pixel's slot list two per trip.  Sorted input makes the first K
-//             hits of a pixel its K nearest, so a pixel closes at K hits (and, from the second chunk on, at the first
-//             record beyond its own K-th key).
-//   merge   : the chunk's per-pixel winners go into the register-resident running top-K (first chunk: plain copy;
-//             later chunks: a 40-exchange bitonic merge network that works in place on the running list).
+//             pixel's mask.  The masks go to LDS as they are (two words per pixel and block) and only a hit count is
+//             kept.  Sorted input makes the first K hits of a pixel its K nearest, so a pixel closes at K hits (and, from
+//             the second chunk on, at the first record beyond its own K-th key).
+//   merge   : every lane walks its mask words for the positions of its first K hits (one count-trailing-zeros step per
+//             winner; extracting hits during the sweep made every lane wait for the one with the most hits, block after
+//             block); the winners' keys go into the register-resident running top-K (first chunk: plain copy; later
+//             chunks: a 40-exchange bitonic merge network that works in place on the running list).
 // The running list is kept in DESCENDING key order: position p holds the pixel's (EP_K-1-p)-th nearest fragment, empty
 // positions (all ones) come first.  With the chunk's winners B in ascending order, min(list[p], B[p]) for every p is
 // then the EP_K smallest keys of both as a rising-then-falling sequence, which the network sorts back to descending
 // order without any scratch registers.
-// LDS per wave = C*16 (sorted records) + max(NB*4, (K+1)*128) (bucket table and slot lists share the space): 8.6 KiB
-// for C = 384, so that four waves per SIMD (16 per CU) fit the 160 KiB of a CU.
+// LDS per wave = C*16 (sorted records) + max(NB*4, C*8) (bucket table, hit masks and threshold tables share the space):
+// 12 KiB for C = 512, three waves per SIMD (12 per CU) in the 160 KiB of a CU.
 // Sorts a list that rises and then falls (the element-wise minimum of a descending list and an ascending one) back into
 // descending order: a bitonic merge for a length that is not a power of two (EP_K = 16 + 4); positions 20 .. 31 would
 // hold minus infinity and never move, so the exchanges with them are left out.
@@ -1400,7 +1404,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 cmax = o > cmax ? o : cmax;
             }
             u64* const line = colband + 64;  // 8 row maxima, 8 column maxima
-            __syncthreads();                 // the merge's reads of the slot lists are done
+            __syncthreads();                 // the merge's reads of the hit masks are done
             if ((lane & 7) == 0) line[lane >> 3] = rmax;
             if (lane < 8) line[8 + lane] = cmax;
             __syncthreads();

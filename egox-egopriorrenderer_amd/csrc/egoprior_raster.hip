@@ -980,17 +980,23 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             if (pos < end) continue;
             break;
         }
-        u64 kmin = ~0ull, kmax = 0ull;
+        // The key range of the chunk from its depths alone (32-bit reductions): every index fits under the largest depth
+        // and above the smallest, and the map below only needs bounds.
+        uint32_t zmin = 0xFFFFFFFFu, zmax = 0u;
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
-            const u64 klo = val[u] ? key[u] : ~0ull, khi = val[u] ? key[u] : 0ull;
-            kmin = klo < kmin ? klo : kmin;
-            kmax = khi > kmax ? khi : kmax;
+            const uint32_t zb = (uint32_t)(key[u] >> 32);
+            zmin = min(zmin, val[u] ? zb : 0xFFFFFFFFu);
+            zmax = max(zmax, val[u] ? zb : 0u);
         }
         EP_STAGE(0)
         EP_PROBE(1, (uint32_t)key[0] ^ rx[0] ^ ry[RPL - 1] ^ (uint32_t)m)
-        kmin = wave_min_u64(kmin);
-        kmax = wave_max_u64(kmax);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            zmin = min(zmin, (uint32_t)__shfl_xor((int)zmin, d));
+            zmax = max(zmax, (uint32_t)__shfl_xor((int)zmax, d));
+        }
+        const u64 kmin = (u64)uniform_u32(zmin) << 32, kmax = ((u64)uniform_u32(zmax) << 32) | 0xFFFFFFFFull;
         // Two-level monotone bucket map.  Level 1: NB equal-width ranges of [kmin, kmax].  Their histogram, and then the
         // table that maps a range to its first bucket and sub-range count, live in the first bytes of S, which is not in
         // use until the scatter.  Range c, which received cc records, is cut into 2^floor(log2 cc) equal sub-ranges, so
@@ -1311,7 +1317,11 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                         hm_hi = bits;
                 }
             }
-            if (cnt >= K || j0 >= jlim) {
+            // Hits beyond a pixel's first K are harmless (only the first K set bits of its masks are ever read), and in the
+            // first chunk every pixel's prefix is the whole chunk, whose padding never hits: only later chunks have to cut
+            // the masks at the end of the pixel's prefix.
+            if (chunk_no == 0) {
+            } else if (j0 >= jlim) {
                 hm_lo = 0u;
                 hm_hi = 0u;
             } else if (jlim - j0 < 64) {  // this lane's prefix ends inside the block

@@ -395,6 +395,54 @@ def test_rasterize_heavy_tiles_are_sliced(engine, mode, splat_variant):
         assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+def test_sliced_tiles_with_exact_and_short_workspaces(engine):
+    """A dense blob whose tiles are sliced, rendered in a workspace sized from the frame's own entry count (exact bits)
+    and in one that holds only 40 % of the entries: the lists are cut, the status word says so, and nothing is read or
+    written out of bounds (every slice's share of a cut list is empty or shortened)."""
+    import ctypes as C
+    from egoprior import _lib, engine as eng
+    L, dev = engine.L, engine.device
+    H, W, ps, K = 40, 48, 4.0, 20
+    rng = np.random.default_rng(31)
+    n = 300_000
+    xy = np.stack([rng.uniform(-0.5, 0.3, n), rng.uniform(-0.3, 0.4, n)], axis=1).astype(F32)
+    ndc = np.concatenate([xy, rng.uniform(1.0, 4.0, (n, 1)).astype(F32)], axis=1)
+    cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    r = O.radius_ndc(ps, H, W)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, K, "scatter")
+    rec = pack_ndc(ndc, cols, dev)
+    rp = eng.make_raster_params(ps, H, W, K=K, colors_gt1=1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ws0 = torch.empty(L.egoprior_raster_workspace_bytes_entries(H, W, n, 0), dtype=torch.uint8, device=dev)
+    entries = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(L.egoprior_count_list_entries(None, C.byref(rp), H, W, C.c_void_p(rec.data_ptr()), n, None, None, 0, None,
+                                             C.c_void_p(entries.data_ptr()), C.c_void_p(ws0.data_ptr()), ws0.numel(), st))
+    need = int(entries.item())
+    assert need > 20 * 32768  # several tiles are long enough to be sliced
+
+    def render(n_entries):
+        ws = torch.empty(L.egoprior_raster_workspace_bytes_entries(H, W, n, n_entries), dtype=torch.uint8, device=dev)
+        idx = torch.empty((H, W, K), dtype=torch.int32, device=dev)
+        zb = torch.empty((H, W, K), dtype=torch.float32, device=dev)
+        ds = torch.empty((H, W, K), dtype=torch.float32, device=dev)
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.egoprior_rasterize_composite(C.byref(rp), H, W, C.c_void_p(rec.data_ptr()), n, None, None, None,
+                                                  C.c_void_p(img.data_ptr()), None, C.c_void_p(idx.data_ptr()),
+                                                  C.c_void_p(zb.data_ptr()), C.c_void_p(ds.data_ptr()),
+                                                  C.c_void_p(status.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), st))
+        torch.cuda.synchronize()
+        return idx.cpu().numpy(), zb.cpu().numpy(), ds.cpu().numpy(), int(status.item())
+
+    idx, zb, ds, status = render(need)
+    assert status == 0 and np.array_equal(idx, ref_idx) and np.array_equal(zb, ref_z) and np.array_equal(ds, ref_d)
+    idx, zb, ds, status = render(need * 2 // 5)
+    assert status == 1
+    assert ((idx >= -1) & (idx < n)).all()                      # what was drawn is still made of real points
+    hit = idx >= 0
+    assert np.array_equal(zb[hit], ndc[idx[hit], 2])            # ... with their own depths
+
+
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_rasterize_random_geometry(engine, seed):
     """Random image sizes (ragged last tiles), point sizes from sub-pixel to a quarter of the image, K of 1, 5 or 20,

@@ -18,6 +18,12 @@
 
 namespace ep {
 
+// A tile-list entry: point index and depth bits, together the 64-bit key (-0.0 -> +0.0, so that key order == float order).
+typedef uint2 ListEntry;
+__device__ __forceinline__ ListEntry make_entry(uint32_t idx, float z) {
+    return make_uint2(idx, __float_as_uint(z == 0.0f ? 0.0f : z));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // camera math (operation order = oracle/oracle.py project_pinhole / project_fisheye)
 // ------------------------------------------------------------------------------------------------------------------
@@ -113,8 +119,9 @@ __device__ __forceinline__ void count_point_global(bool live, int tx0, int tx1, 
 // The same run grouping straight on the global cursors (no LDS stage): one returning global atomic per run and tile.
 __device__ __forceinline__ void bin_point_runs_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
                                                       uint32_t* __restrict__ cursor,
-                                                      const uint32_t* __restrict__ tile_start, uint2* __restrict__ list,
-                                                      uint32_t capacity, uint2 entry) {
+                                                      const uint32_t* __restrict__ tile_start,
+                                                      ListEntry* __restrict__ list, uint32_t capacity,
+                                                      ListEntry entry) {
     const int lane = lane_id();
     const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
     if (!live) return;
@@ -390,8 +397,8 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
 __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_point* __restrict__ ndc, int64_t cap,
                                                    const int32_t* __restrict__ d_n,
                                                    const uint32_t* __restrict__ tile_start,
-                                                   uint32_t* __restrict__ tile_cursor, uint2* __restrict__ list,
-                                                   uint32_t capacity) {
+                                                   uint32_t* __restrict__ tile_cursor,
+                                                   ListEntry* __restrict__ list, uint32_t capacity) {
     const int64_t n = live_count(d_n, cap);
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
@@ -407,9 +414,7 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
             const int64_t i = base + k * 256 + threadIdx.x;
             int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
             const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
-            // list entry: point index, depth bits (-0.0 -> +0.0 so that key order == float order)
-            const float oz = pin[k].z;
-            const uint2 entry = make_uint2((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz));
+            const ListEntry entry = make_entry((uint32_t)i, pin[k].z);
             bin_point_runs_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_cursor, tile_start, list, capacity, entry);
         }
     }
@@ -424,7 +429,7 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
                                                           int64_t cap, const int32_t* __restrict__ d_n,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ wg_piece,
-                                                          uint2* __restrict__ list, uint32_t capacity) {
+                                                          ListEntry* __restrict__ list, uint32_t capacity) {
     extern __shared__ uint32_t cur[];
     const int n_tiles = g.tiles_x * g.tiles_y;
     const int n_words = (n_tiles + 1) >> 1;
@@ -448,8 +453,7 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
             const int64_t i = base + k * 256 + threadIdx.x;
             int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
             const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
-            const float oz = pin[k].z;
-            const uint2 entry = make_uint2((uint32_t)i, __float_as_uint(oz == 0.0f ? 0.0f : oz));
+            const ListEntry entry = make_entry((uint32_t)i, pin[k].z);
             const LaneRun r = lane_runs(hit, tx0, tx1, ty0, ty1);
             if (!hit) continue;
             for (int ty = ty0; ty <= ty1; ++ty) {
@@ -486,16 +490,38 @@ typedef unsigned long long u64;
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
-// ... and the cycles all waves spent in each stage: gather, sort, sweep, extraction + merge, compositor
-__device__ unsigned long long g_stage_cycles[8];
+// ... and the cycles all waves spent in each stage: gather, sort, sweep, extraction + merge, compositor; [5] waves,
+// [6] chunks, [7] chunks sorted by the bitonic fallback, [8] buckets ranked by the whole wave, [9] records in those,
+// [10] records sorted, [11..14] gather: cycles waiting for keys, for x, y, in the tests, in the staging, [15] batches
+__device__ unsigned long long g_stage_cycles[16];
 #define EP_STAGE(i_)                                                 \
     {                                                                \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
         stage_cyc[i_] += now_ - stage_t;                             \
         stage_t = now_;                                              \
     }
+#define EP_DIAG_FLUSH()                                                                         \
+    {                                                                                           \
+        if (lane == 0) {                                                                        \
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[i], stage_cyc[i]);            \
+            atomicAdd(&g_stage_cycles[5], 1ull);                                                \
+            atomicAdd(&g_stage_cycles[6], (unsigned long long)chunk_no);                        \
+            atomicAdd(&g_stage_cycles[7], (unsigned long long)dbg_bitonic);                     \
+            atomicAdd(&g_stage_cycles[8], (unsigned long long)dbg_wave_buckets);                \
+            atomicAdd(&g_stage_cycles[9], (unsigned long long)dbg_wave_records);                \
+            atomicAdd(&g_stage_cycles[10], (unsigned long long)dbg_sorted);                     \
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[11 + i], dbg_g[i]);           \
+        }                                                                                       \
+        if (lane == 0 && blockIdx.x < 8192u) {                                                  \
+            g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile | (slice_no << 24);               \
+            g_tile_times[blockIdx.x * 4 + 1] = tt_records;                                      \
+            g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);  \
+            g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;                              \
+        }                                                                                       \
+    }
 #else
 #define EP_STAGE(i_)
+#define EP_DIAG_FLUSH()
 #endif
 // Diagnostic build only: STOP > 0 instantiations of the sweep kernel are instruction-count probes (option "splat_variant"
 // 11..14) whose chunk loop ends after the load (1), sort (2) or sweep (3) stage, or that skip the compositor (4); a
@@ -681,7 +707,7 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
                                                      const egoprior_point* __restrict__ ndc,
                                                      const uint32_t* __restrict__ tile_start,
                                                      const uint32_t* __restrict__ tile_order,
-                                                     const uint2* __restrict__ list, uint32_t capacity,
+                                                     const ListEntry* __restrict__ list, uint32_t capacity,
                                                      const int32_t* __restrict__ d_flags_a,
                                                      const int32_t* __restrict__ d_flags_b, SplatOut out) {
     __shared__ float4 recs[64];
@@ -707,7 +733,7 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
         const uint32_t nrec = min(64u, end - c0);
         __syncthreads();
         if ((uint32_t)lane < nrec) {
-            const uint2 e = list[c0 + lane];  // point index, depth bits
+            const ListEntry e = list[c0 + lane];
             const float2v xy = *reinterpret_cast<const float2v*>(&ndc[e.x].x);
             recs[lane] = make_float4(xy.x, xy.y, __uint_as_float(e.y), __uint_as_float(e.x));
         }
@@ -807,7 +833,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
                                                     const uint32_t* __restrict__ tile_order,
-                                                    const uint2* __restrict__ list, uint32_t capacity,
+                                                    const ListEntry* __restrict__ list, uint32_t capacity,
                                                     const int32_t* __restrict__ d_flags_a,
                                                     const int32_t* __restrict__ d_flags_b, SlicePlan sp, SplatOut out) {
     static_assert(C % 64 == 0 && NB % 64 == 0 && C <= 1024 && (NB & (NB - 1)) == 0 && NB >= C, "geometry");
@@ -875,6 +901,8 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     const unsigned long long tt0 = __builtin_readcyclecounter();
     const uint32_t tt_records = end - pos;
     unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
+    uint32_t dbg_bitonic = 0, dbg_wave_buckets = 0, dbg_wave_records = 0, dbg_sorted = 0;
+    unsigned long long dbg_g[5] = {0, 0, 0, 0, 0};
 #endif
 
     // Per-record threshold tables (rebuilt after every merge, read while the next chunk is gathered; they live in `aux`,
@@ -897,24 +925,37 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         bool val[RPL];
         int m = 0;
         __syncthreads();  // the previous chunk's readers of S are done; the threshold tables are written
-        // One batch: up to nb keys per lane from `pos` on, tested against the thresholds; ok[] marks the survivors, whose
-        // number is returned.  All the loads of a round trip are issued before any of them is used.
-        auto gather_batch = [&](int nb, u64(&k)[RPL], uint32_t(&x)[RPL], uint32_t(&y)[RPL], bool(&ok)[RPL]) -> int {
+        // A batch = the C list entries from p on, RPL per lane.  Its keys are fetched first (issue_keys), then the x, y of
+        // the keys below the tile's threshold, and while those are on their way the keys of the batch after it are
+        // requested, so that only the first batch of a wave waits for two round trips in a row.  All loads are
+        // unconditional (clamped addresses): a load under a branch would make every later wait count conservatively.
+        auto issue_keys = [&](uint32_t p, u64(&k)[RPL], bool(&ok)[RPL]) {
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
-                const uint32_t e = pos + (uint32_t)(u * 64 + lane);
-                ok[u] = (u < nb) && (e < end);
-                // unconditional (clamped); an entry is (index, depth bits) = the key as it is
-                k[u] = reinterpret_cast<const u64*>(list)[ok[u] ? e : end - 1u];
+                const uint32_t e = p + (uint32_t)(u * 64 + lane);
+                ok[u] = e < end;
+                k[u] = reinterpret_cast<const u64*>(list)[ok[u] ? e : end - 1u];  // (index, depth bits) = the key as it is
             }
-            // second round trip: x, y of the entries that pass the tile's threshold (the others read record 0)
+        };
+        // tests the batch k against the thresholds; ok[] marks the survivors, whose number is returned; requests the keys
+        // of the batch at p_next into kn on the way
+        auto finish_batch = [&](const u64(&k)[RPL], uint32_t(&x)[RPL], uint32_t(&y)[RPL], bool(&ok)[RPL], uint32_t p_next,
+                                u64(&kn)[RPL], bool(&okn)[RPL]) -> int {
+#ifdef EP_TILE_TIMES
+            const unsigned long long g_t0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
-                const bool want = ok[u] && (k[u] < T);
+                const bool want = ok[u] && (k[u] < T);  // (the others read record 0)
                 const float2v xy = *reinterpret_cast<const float2v*>(&ndc[want ? (uint32_t)k[u] : 0u].x);
                 x[u] = __float_as_uint(xy.x);
                 y[u] = __float_as_uint(xy.y);
             }
+            issue_keys(p_next, kn, okn);
+#ifdef EP_TILE_TIMES
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            const unsigned long long g_t2 = __builtin_readcyclecounter();
+#endif
             int s = 0;
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
@@ -934,36 +975,70 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 ok[u] = o;
                 s += __popcll(__ballot(o));
             }
+#ifdef EP_TILE_TIMES
+            dbg_g[1] += g_t2 - g_t0;
+            dbg_g[2] += __builtin_readcyclecounter() - g_t2;
+            dbg_g[4] += 1;
+#endif
             return s;
         };
-        auto stage_batch = [&](const u64(&k)[RPL], const uint32_t(&x)[RPL], const uint32_t(&y)[RPL], const bool(&ok)[RPL]) {
+        // Compacts the survivors of a batch into S, row by row (a row = the 64 entries of one load), for as long as whole
+        // rows fit into the chunk; returns the number of rows taken.  The list position moves on by those rows only, so
+        // a row that did not fit is simply fetched again for the next chunk (it is in the caches by then).
+        auto stage_batch = [&](const u64(&k)[RPL], const uint32_t(&x)[RPL], const uint32_t(&y)[RPL],
+                               const bool(&ok)[RPL]) -> int {
+            int rows = 0;
+            bool open = true;  // wave-uniform
 #pragma unroll
             for (int u = 0; u < RPL; ++u) {
                 const u64 bal = __ballot(ok[u]);
-                if (ok[u]) {
-                    const int dst = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    S[dst] = make_uint4((uint32_t)k[u], (uint32_t)(k[u] >> 32), x[u], y[u]);
+                const int c = __popcll(bal);
+                open = open && (m + c <= C);
+                if (open) {
+                    if (ok[u]) {
+                        const int dst = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        S[dst] = make_uint4((uint32_t)k[u], (uint32_t)(k[u] >> 32), x[u], y[u]);
+                    }
+                    m += c;
+                    ++rows;
                 }
-                m += __popcll(bal);
             }
+            return rows;
         };
-        const int s0 = gather_batch(RPL, key, rx, ry, val);
+        u64 kn[RPL];  // the keys of the batch after the one at work
+        bool okn[RPL];
+#ifdef EP_TILE_TIMES
+        const unsigned long long g_k0 = __builtin_readcyclecounter();
+#endif
+        issue_keys(pos, key, val);
+#ifdef EP_TILE_TIMES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg_g[0] += __builtin_readcyclecounter() - g_k0;
+#endif
+        const int s0 = finish_batch(key, rx, ry, val, pos + (uint32_t)C, kn, okn);
         pos += C;
         if (pos >= end || s0 > C - 64) {
             // the batch ends the list or (nearly) fills the chunk by itself: it is sorted straight from the registers
+            // (the keys requested on the way are dropped: they are the next chunk's first batch, in the caches by then)
             m = s0;
         } else {
-            stage_batch(key, rx, ry, val);
-            while (pos < end) {
-                const int nb = (int)uniform_u32((uint32_t)((C - m) >> 6));  // keys per lane that still fit
-                if (nb == 0) break;
+            stage_batch(key, rx, ry, val);  // s0 <= C - 64: every row fits
+            // Whole batches from here on, however little room is left: a batch costs the same memory round trips
+            // whatever its size, and with a few keys in a hundred passing the thresholds the chunk takes many of them.
+            while (pos < end && m <= C - 64) {
                 u64 k2[RPL];
                 uint32_t x2[RPL], y2[RPL];
                 bool ok2[RPL];
-                gather_batch(nb, k2, x2, y2, ok2);
-                stage_batch(k2, x2, y2, ok2);
-                pos += (uint32_t)nb * 64u;
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) {
+                    k2[u] = kn[u];
+                    ok2[u] = okn[u];
+                }
+                finish_batch(k2, x2, y2, ok2, pos + (uint32_t)C, kn, okn);
+                const int rows = stage_batch(k2, x2, y2, ok2);
+                pos += (uint32_t)rows * 64u;
+                if (rows < RPL) break;
             }
             __syncthreads();
 #pragma unroll
@@ -990,6 +1065,9 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             zmax = max(zmax, val[u] ? zb : 0u);
         }
         EP_STAGE(0)
+#ifdef EP_TILE_TIMES
+        dbg_sorted += (uint32_t)m;
+#endif
         EP_PROBE(1, (uint32_t)key[0] ^ rx[0] ^ ry[RPL - 1] ^ (uint32_t)m)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -1170,6 +1248,10 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     mk &= mk - 1u;
                     const int bs = (b == 0) ? 0 : (int)bkt[b - 1];
                     const int n = (int)bkt[b] - bs;  // EP_RANK_SELF < n <= EP_RANK_WAVE
+#ifdef EP_TILE_TIMES
+                    ++dbg_wave_buckets;
+                    dbg_wave_records += (uint32_t)n;
+#endif
                     __syncthreads();
                     uint4 mine[EP_RANK_WAVE / 64];
                     int rank[EP_RANK_WAVE / 64];
@@ -1194,6 +1276,9 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             // ascending compare-exchanges only (each merge starts with a flip stage), so that the positions from C up to
             // the next power of two can stay virtual: they would hold "nothing" records, which never move.
             constexpr int P2 = next_pow2(C);
+#ifdef EP_TILE_TIMES
+            ++dbg_bitonic;
+#endif
             for (int i = m + lane; i < C; i += 64) S[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0x7F800000u, 0x7F800000u);
             __syncthreads();
             for (int k2 = 2; k2 <= P2; k2 <<= 1) {
@@ -1444,7 +1529,10 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         uint32_t before = 0u;
         if (lane == 0) before = atomicAdd(&sp.done[tile], 1u);
         before = uniform_u32(before);
-        if (before != n_slices - 1u) return;
+        if (before != n_slices - 1u) {
+            EP_DIAG_FLUSH()
+            return;
+        }
         __threadfence();  // and the others' lists are read only after their arrivals have been seen
         const uint32_t first = sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
@@ -1481,16 +1569,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     }
 #ifdef EP_TILE_TIMES
     EP_STAGE(4)
-    if (lane == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[i], stage_cyc[i]);
-        atomicAdd(&g_stage_cycles[5], 1ull);
-    }
-    if (lane == 0 && blockIdx.x < 8192u) {
-        g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile | (slice_no << 24);
-        g_tile_times[blockIdx.x * 4 + 1] = tt_records;
-        g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);
-        g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;
-    }
+    EP_DIAG_FLUSH()
 #endif
 }
 
@@ -1565,7 +1644,7 @@ struct RasterWs {
     int32_t* total;         // 1 (+ padding)
     uint32_t* pieces;       // workgroups x tiles words: where each counting workgroup's entries start inside each tile's
                             // list (k_tile_fill_pieces); NULL when that pass is not used
-    uint2* list;            // capacity entries: (point index, depth bits)
+    ep::ListEntry* list;    // capacity entries
     uint64_t capacity;
     ep::SlicePlan slices;   // max_slots == 0: the workspace has no room for it
 };
@@ -1608,7 +1687,7 @@ size_t pieces_bytes(int n_tiles, int64_t n) {
 }
 
 size_t raster_ws_bytes_for(int n_tiles, int64_t n, uint64_t entries) {
-    return raster_header_bytes(n_tiles) + pieces_bytes(n_tiles, n) + align_up((size_t)entries * sizeof(uint2), 256) +
+    return raster_header_bytes(n_tiles) + pieces_bytes(n_tiles, n) + align_up((size_t)entries * sizeof(ep::ListEntry), 256) +
            slice_area_bytes(n_tiles, entries) + 256;
 }
 
@@ -1629,14 +1708,14 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
         r.pieces = (uint32_t*)((char*)ws + off);
         off += pb;
     }
-    r.list = (uint2*)((char*)ws + off);
+    r.list = (ep::ListEntry*)((char*)ws + off);
     const size_t rest = bytes - off;
-    uint64_t cap = rest / sizeof(uint2);
+    uint64_t cap = rest / sizeof(ep::ListEntry);
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
     r.slices = ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
     if (tn.slices != 0 && tn.splat_variant != 1) {
         // largest capacity whose lists and slice area both fit (the need grows with the capacity: bisection)
-        auto need = [&](uint64_t c) { return align_up((size_t)c * sizeof(uint2), 256) + slice_area_bytes(n_tiles, c); };
+        auto need = [&](uint64_t c) { return align_up((size_t)c * sizeof(ep::ListEntry), 256) + slice_area_bytes(n_tiles, c); };
         if (need(64) <= rest) {
             uint64_t lo = 64, hi = cap;  // need(lo) fits
             while (lo < hi) {
@@ -1648,7 +1727,7 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
             }
             cap = lo;
             const uint64_t slots = slice_slots_for(cap);
-            char* q = (char*)ws + off + align_up((size_t)cap * sizeof(uint2), 256);
+            char* q = (char*)ws + off + align_up((size_t)cap * sizeof(ep::ListEntry), 256);
             r.slices.slot_base = (uint32_t*)q;
             r.slices.done = r.slices.slot_base + n_tiles;
             r.slices.total = r.slices.done + n_tiles;
@@ -1938,10 +2017,10 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
 }
 
 #ifdef EP_TILE_TIMES
-extern "C" int egoprior_debug_stage_cycles(unsigned long long* host8, int reset) {
-    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(ep::g_stage_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+extern "C" int egoprior_debug_stage_cycles(unsigned long long* host16, int reset) {
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(ep::g_stage_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -3;
     }
     return 0;

@@ -53,7 +53,7 @@ print(f"render_frame: {ev0.elapsed_time(ev1) / 3:.2f} ms")
 if "tiletimes" in str(_lib.LIB_PATH):
     import ctypes as C
     D = C.CDLL(str(_lib.LIB_PATH))
-    cbuf = (C.c_uint64 * 8)()
+    cbuf = (C.c_uint64 * 16)()
     D.egoprior_debug_stage_cycles(cbuf, 1)
     E.render_frame(cam, rp, bg)
     torch.cuda.synchronize()
@@ -62,6 +62,8 @@ if "tiletimes" in str(_lib.LIB_PATH):
     tot = max(sum(c[:5]), 1)
     print("wave cycles by stage: " + ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(
         ("gather", "sort", "sweep+append", "merge", "compositor"), c[:5])) + f"; total {tot:.4g} over {c[5]} waves")
+    print(f"chunks {c[6]}, of which bitonic {c[7]}; buckets ranked by the wave {c[8]} holding {c[9]} records; records sorted {c[10]}")
+    print(f"gather: {c[15]} batches; cycles waiting for keys {c[11]:.4g}, for x, y {c[12]:.4g}, tests {c[13]:.4g}")
     n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
     buf = (C.c_uint32 * (4 * n_tiles))()
     assert D.egoprior_debug_tile_times(buf, 4 * n_tiles) == 0

@@ -490,10 +490,13 @@ typedef unsigned long long u64;
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
+// ... and when each of the first 16384 waves started and ended (low 32 bits of the 100 MHz real-time counter)
+__device__ uint32_t g_wave_span[16384 * 2];
 // ... and the cycles all waves spent in each stage: gather, sort, sweep, extraction + merge, compositor; [5] waves,
 // [6] chunks, [7] chunks sorted by the bitonic fallback, [8] buckets ranked by the whole wave, [9] records in those,
-// [10] records sorted, [11..14] gather: cycles waiting for keys, for x, y, in the tests, in the staging, [15] batches
-__device__ unsigned long long g_stage_cycles[16];
+// [10] records sorted, [11..14] gather: cycles waiting for keys, for x, y, in the tests, in the staging, [15] batches,
+// [16..19] merge stage: mask walk, key reads + network, tile threshold, band tables
+__device__ unsigned long long g_stage_cycles[24];
 #define EP_STAGE(i_)                                                 \
     {                                                                \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -511,12 +514,17 @@ __device__ unsigned long long g_stage_cycles[16];
             atomicAdd(&g_stage_cycles[9], (unsigned long long)dbg_wave_records);                \
             atomicAdd(&g_stage_cycles[10], (unsigned long long)dbg_sorted);                     \
             for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[11 + i], dbg_g[i]);           \
+            for (int i = 0; i < 4; ++i) atomicAdd(&g_stage_cycles[16 + i], dbg_m[i]);           \
         }                                                                                       \
         if (lane == 0 && blockIdx.x < 8192u) {                                                  \
             g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile | (slice_no << 24);               \
             g_tile_times[blockIdx.x * 4 + 1] = tt_records;                                      \
             g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);  \
             g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;                              \
+        }                                                                                       \
+        if (lane == 0 && blockIdx.x < 16384u) {                                                 \
+            g_wave_span[blockIdx.x * 2 + 0] = (uint32_t)tt0_real;                               \
+            g_wave_span[blockIdx.x * 2 + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();       \
         }                                                                                       \
     }
 #else
@@ -899,10 +907,11 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     int chunk_no = 0;
 #ifdef EP_TILE_TIMES
     const unsigned long long tt0 = __builtin_readcyclecounter();
+    const unsigned long long tt0_real = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same on every XCD
     const uint32_t tt_records = end - pos;
     unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
     uint32_t dbg_bitonic = 0, dbg_wave_buckets = 0, dbg_wave_records = 0, dbg_sorted = 0;
-    unsigned long long dbg_g[5] = {0, 0, 0, 0, 0};
+    unsigned long long dbg_g[5] = {0, 0, 0, 0, 0}, dbg_m[4] = {0, 0, 0, 0};
 #endif
 
     // Per-record threshold tables (rebuilt after every merge, read while the next chunk is gathered; they live in `aux`,
@@ -1432,6 +1441,17 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 
         // ---- merge the chunk's winners into the running list -------------------------------------------------------
         const int won = inside ? cnt : 0;  // at most K, and never more than the lane's hits in the masks
+#ifdef EP_TILE_TIMES
+        unsigned long long m_t = __builtin_readcyclecounter();
+#define EP_MSTAGE(i_)                                                 \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        dbg_m[i_] += now_ - m_t;                                      \
+        m_t = now_;                                                   \
+    }
+#else
+#define EP_MSTAGE(i_)
+#endif
         // positions in S of the lane's winners, in ascending key order: the first `won` set bits of its masks
         uint32_t widx[EP_K];
         {
@@ -1447,6 +1467,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                 }
             }
         }
+        EP_MSTAGE(0)
         if (chunk_no == 0) {
 #pragma unroll
             for (int k = 0; k < EP_K; ++k) {
@@ -1468,6 +1489,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             merge_network_desc(kl);
         }
         ++chunk_no;
+        EP_MSTAGE(1)
         if (pos < end) {
             u64 mine = 0ull;  // outside pixels never raise the threshold
             if (inside) {
@@ -1478,6 +1500,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             }
             T = wave_max_u64(mine);
         }
+        EP_MSTAGE(2)
         if (pos < end && chunk_no > 1) {
             // threshold tables for the next gather: row / column maxima of the K-th keys, then every band of them
             u64 mine = 0ull;
@@ -1512,6 +1535,8 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
             rowband[lane] = rb;
             colband[lane] = cb;
         }
+        EP_MSTAGE(3)
+#undef EP_MSTAGE
         EP_STAGE(3)
     }
 #ifdef EP_TILE_TIMES
@@ -2017,13 +2042,16 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
 }
 
 #ifdef EP_TILE_TIMES
-extern "C" int egoprior_debug_stage_cycles(unsigned long long* host16, int reset) {
-    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(ep::g_stage_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
+extern "C" int egoprior_debug_stage_cycles(unsigned long long* host24, int reset) {
+    if (hipMemcpyFromSymbol(host24, HIP_SYMBOL(ep::g_stage_cycles), 24 * sizeof(unsigned long long)) != hipSuccess) return -3;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -3;
     }
     return 0;
+}
+extern "C" int egoprior_debug_wave_spans(uint32_t* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_wave_span), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
 }
 extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_tile_times), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;

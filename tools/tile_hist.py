@@ -53,7 +53,7 @@ print(f"render_frame: {ev0.elapsed_time(ev1) / 3:.2f} ms")
 if "tiletimes" in str(_lib.LIB_PATH):
     import ctypes as C
     D = C.CDLL(str(_lib.LIB_PATH))
-    cbuf = (C.c_uint64 * 16)()
+    cbuf = (C.c_uint64 * 24)()
     D.egoprior_debug_stage_cycles(cbuf, 1)
     E.render_frame(cam, rp, bg)
     torch.cuda.synchronize()
@@ -64,6 +64,7 @@ if "tiletimes" in str(_lib.LIB_PATH):
         ("gather", "sort", "sweep+append", "merge", "compositor"), c[:5])) + f"; total {tot:.4g} over {c[5]} waves")
     print(f"chunks {c[6]}, of which bitonic {c[7]}; buckets ranked by the wave {c[8]} holding {c[9]} records; records sorted {c[10]}")
     print(f"gather: {c[15]} batches; cycles waiting for keys {c[11]:.4g}, for x, y {c[12]:.4g}, tests {c[13]:.4g}")
+    print(f"merge stage: mask walk {c[16]:.4g}, key reads + network {c[17]:.4g}, tile threshold {c[18]:.4g}, band tables {c[19]:.4g}")
     n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
     buf = (C.c_uint32 * (4 * n_tiles))()
     assert D.egoprior_debug_tile_times(buf, 4 * n_tiles) == 0
@@ -73,3 +74,18 @@ if "tiletimes" in str(_lib.LIB_PATH):
     for o in np.argsort(-cyc)[:10]:
         print(f"  tile {tile[o]:5d} records {rec[o]:7d} chunks {chunks[o]:4d} cycles {cyc[o]:9d} "
               f"({cyc[o] / max(chunks[o], 1):7.0f} per chunk, {rec[o] / max(chunks[o], 1):6.0f} records per chunk)")
+    # occupancy over the launch, from the start and end of every wave (first 16384 workgroups)
+    nw = min(int(c[5]), 16384)
+    sb = (C.c_uint32 * (2 * 16384))()
+    assert D.egoprior_debug_wave_spans(sb, 2 * 16384) == 0
+    sp = np.frombuffer(sb, dtype=np.uint32).reshape(-1, 2).astype(np.int64)
+    sp = sp[(sp[:, 1] != 0)]
+    t0 = sp[:, 0].min()
+    st, en = (sp[:, 0] - t0) & 0xFFFFFFFF, (sp[:, 1] - t0) & 0xFFFFFFFF
+    span = en.max()
+    print(f"{len(sp)} waves ran; launch span {span / 100.0:.1f} us; sum of wave ticks {int((en - st).sum())} "
+          f"= {100 * (en - st).sum() / (span * 3072.0):.1f}% of 3072 slots")
+    edges = np.linspace(0, span, 21)
+    occ = [int(((st < b) & (en > a)).sum()) for a, b in zip(edges[:-1], edges[1:])]
+    print("waves alive per 5% of the launch:", occ)
+    print("start times percentiles (% of span):", [round(100 * float(np.percentile(st, q)) / span, 1) for q in (10, 25, 50, 75, 90, 99)])

@@ -487,11 +487,23 @@ struct SplatOut {
 
 typedef unsigned long long u64;
 
+#if defined(EP_TILE_TIMES) || defined(EP_WAVE_SPANS)
+// Diagnostic builds only: when each of the first 16384 waves of the last k_splat_sweep launch started and ended (low 32
+// bits of the 100 MHz real-time counter, the same on every XCD), its list entries and its chunks.  -DEP_WAVE_SPANS alone
+// adds two counter reads and one 16-byte store per wave: the launch keeps its shape.
+__device__ uint4 g_wave_span[16384];
+#define EP_SPAN_BEGIN() const unsigned long long tt0_real = __builtin_amdgcn_s_memrealtime();
+#define EP_SPAN_END()                                                                                              \
+    if (lane == 0 && blockIdx.x < 16384u)                                                                          \
+        g_wave_span[blockIdx.x] = make_uint4((uint32_t)tt0_real, (uint32_t)__builtin_amdgcn_s_memrealtime(), span_records, \
+                                             (uint32_t)chunk_no);
+#else
+#define EP_SPAN_BEGIN()
+#define EP_SPAN_END()
+#endif
 #ifdef EP_TILE_TIMES
 // Diagnostic build only: (tile, records, cycles, chunks) of every wave of the last k_splat_sweep launch.
 __device__ uint32_t g_tile_times[8192 * 4];
-// ... and when each of the first 16384 waves started and ended (low 32 bits of the 100 MHz real-time counter)
-__device__ uint32_t g_wave_span[16384 * 2];
 // ... and the cycles all waves spent in each stage: gather, sort, sweep, extraction + merge, compositor; [5] waves,
 // [6] chunks, [7] chunks sorted by the bitonic fallback, [8] buckets ranked by the whole wave, [9] records in those,
 // [10] records sorted, [11..14] gather: cycles waiting for keys, for x, y, in the tests, in the staging, [15] batches,
@@ -521,10 +533,6 @@ __device__ unsigned long long g_stage_cycles[24];
             g_tile_times[blockIdx.x * 4 + 1] = tt_records;                                      \
             g_tile_times[blockIdx.x * 4 + 2] = (uint32_t)(__builtin_readcyclecounter() - tt0);  \
             g_tile_times[blockIdx.x * 4 + 3] = (uint32_t)chunk_no;                              \
-        }                                                                                       \
-        if (lane == 0 && blockIdx.x < 16384u) {                                                 \
-            g_wave_span[blockIdx.x * 2 + 0] = (uint32_t)tt0_real;                               \
-            g_wave_span[blockIdx.x * 2 + 1] = (uint32_t)__builtin_amdgcn_s_memrealtime();       \
         }                                                                                       \
     }
 #else
@@ -905,9 +913,12 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     if (end > capacity) end = capacity;
     if (pos > end) pos = end;
     int chunk_no = 0;
+#if defined(EP_TILE_TIMES) || defined(EP_WAVE_SPANS)
+    const uint32_t span_records = end - pos;
+#endif
+    EP_SPAN_BEGIN()
 #ifdef EP_TILE_TIMES
     const unsigned long long tt0 = __builtin_readcyclecounter();
-    const unsigned long long tt0_real = __builtin_amdgcn_s_memrealtime();  // 100 MHz, the same on every XCD
     const uint32_t tt_records = end - pos;
     unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
     uint32_t dbg_bitonic = 0, dbg_wave_buckets = 0, dbg_wave_records = 0, dbg_sorted = 0;
@@ -1556,6 +1567,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         before = uniform_u32(before);
         if (before != n_slices - 1u) {
             EP_DIAG_FLUSH()
+            EP_SPAN_END()
             return;
         }
         __threadfence();  // and the others' lists are read only after their arrivals have been seen
@@ -1596,6 +1608,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     EP_STAGE(4)
     EP_DIAG_FLUSH()
 #endif
+    EP_SPAN_END()
 }
 
 }  // namespace ep
@@ -2050,10 +2063,19 @@ extern "C" int egoprior_debug_stage_cycles(unsigned long long* host24, int reset
     }
     return 0;
 }
-extern "C" int egoprior_debug_wave_spans(uint32_t* host, int n_words) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_wave_span), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
-}
 extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_tile_times), sizeof(uint32_t) * (size_t)n_words) == hipSuccess ? 0 : -3;
+}
+#endif
+#if defined(EP_TILE_TIMES) || defined(EP_WAVE_SPANS)
+// (start, end, list entries, chunks) of the first n_waves <= 16384 waves of the last splat launch; reset = 1 clears them
+extern "C" int egoprior_debug_wave_spans(uint32_t* host, int n_waves, int reset) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_wave_span), sizeof(uint4) * (size_t)n_waves) != hipSuccess) return -3;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ep::g_wave_span)) != hipSuccess) return -3;
+        if (hipMemset(p, 0, sizeof(uint4) * 16384) != hipSuccess) return -3;
+    }
+    return 0;
 }
 #endif

@@ -74,18 +74,3 @@ if "tiletimes" in str(_lib.LIB_PATH):
     for o in np.argsort(-cyc)[:10]:
         print(f"  tile {tile[o]:5d} records {rec[o]:7d} chunks {chunks[o]:4d} cycles {cyc[o]:9d} "
               f"({cyc[o] / max(chunks[o], 1):7.0f} per chunk, {rec[o] / max(chunks[o], 1):6.0f} records per chunk)")
-    # occupancy over the launch, from the start and end of every wave (first 16384 workgroups)
-    nw = min(int(c[5]), 16384)
-    sb = (C.c_uint32 * (2 * 16384))()
-    assert D.egoprior_debug_wave_spans(sb, 2 * 16384) == 0
-    sp = np.frombuffer(sb, dtype=np.uint32).reshape(-1, 2).astype(np.int64)
-    sp = sp[(sp[:, 1] != 0)]
-    t0 = sp[:, 0].min()
-    st, en = (sp[:, 0] - t0) & 0xFFFFFFFF, (sp[:, 1] - t0) & 0xFFFFFFFF
-    span = en.max()
-    print(f"{len(sp)} waves ran; launch span {span / 100.0:.1f} us; sum of wave ticks {int((en - st).sum())} "
-          f"= {100 * (en - st).sum() / (span * 3072.0):.1f}% of 3072 slots")
-    edges = np.linspace(0, span, 21)
-    occ = [int(((st < b) & (en > a)).sum()) for a, b in zip(edges[:-1], edges[1:])]
-    print("waves alive per 5% of the launch:", occ)
-    print("start times percentiles (% of span):", [round(100 * float(np.percentile(st, q)) / span, 1) for q in (10, 25, 50, 75, 90, 99)])

@@ -492,13 +492,26 @@ typedef unsigned long long u64;
 // bits of the 100 MHz real-time counter, the same on every XCD), its list entries and its chunks.  -DEP_WAVE_SPANS alone
 // adds two counter reads and one 16-byte store per wave: the launch keeps its shape.
 __device__ uint4 g_wave_span[16384];
-#define EP_SPAN_BEGIN() const unsigned long long tt0_real = __builtin_amdgcn_s_memrealtime();
+__device__ uint4 g_wave_chunk_end[16384];  // ... and when its first four chunks ended
+#define EP_SPAN_BEGIN()                                                     \
+    const unsigned long long tt0_real = __builtin_amdgcn_s_memrealtime(); \
+    uint32_t span_chunk_end[4] = {0u, 0u, 0u, 0u};
+#define EP_SPAN_CHUNK()                                                                      \
+    {                                                                                        \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memrealtime();                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) if (chunk_no - 1 == i_) span_chunk_end[i_] = now_; \
+    }
 #define EP_SPAN_END()                                                                                              \
     if (lane == 0 && blockIdx.x < 16384u)                                                                          \
+    {                                                                                                              \
         g_wave_span[blockIdx.x] = make_uint4((uint32_t)tt0_real, (uint32_t)__builtin_amdgcn_s_memrealtime(), span_records, \
-                                             (uint32_t)chunk_no);
+                                             (uint32_t)chunk_no);                                                  \
+        g_wave_chunk_end[blockIdx.x] =                                                                             \
+            make_uint4(span_chunk_end[0], span_chunk_end[1], span_chunk_end[2], span_chunk_end[3]);                \
+    }
 #else
 #define EP_SPAN_BEGIN()
+#define EP_SPAN_CHUNK()
 #define EP_SPAN_END()
 #endif
 #ifdef EP_TILE_TIMES
@@ -1549,6 +1562,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         EP_MSTAGE(3)
 #undef EP_MSTAGE
         EP_STAGE(3)
+        EP_SPAN_CHUNK()
     }
 #ifdef EP_TILE_TIMES
     if (STOP >= 1 && STOP <= 4) {
@@ -2069,6 +2083,9 @@ extern "C" int egoprior_debug_tile_times(uint32_t* host, int n_words) {
 #endif
 #if defined(EP_TILE_TIMES) || defined(EP_WAVE_SPANS)
 // (start, end, list entries, chunks) of the first n_waves <= 16384 waves of the last splat launch; reset = 1 clears them
+extern "C" int egoprior_debug_wave_chunk_ends(uint32_t* host, int n_waves) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_wave_chunk_end), sizeof(uint4) * (size_t)n_waves) == hipSuccess ? 0 : -3;
+}
 extern "C" int egoprior_debug_wave_spans(uint32_t* host, int n_waves, int reset) {
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ep::g_wave_span), sizeof(uint4) * (size_t)n_waves) != hipSuccess) return -3;
     if (reset) {

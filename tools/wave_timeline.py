@@ -53,7 +53,11 @@ E.render_frame(cam, rp, bg)
 ev1.record()
 torch.cuda.synchronize()
 assert spans(buf, 16384, 0) == 0
+cbuf = (C.c_uint32 * (4 * 16384))()
+assert C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_wave_chunk_ends(cbuf, 16384) == 0
 a = np.frombuffer(buf, dtype=np.uint32).reshape(-1, 4).astype(np.int64)
+ce = np.frombuffer(cbuf, dtype=np.uint32).reshape(-1, 4).astype(np.int64)
+ce = ce[a[:, 1] != 0]
 a = a[a[:, 1] != 0]
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0) & 0xFFFFFFFF, (a[:, 1] - t0) & 0xFFFFFFFF
@@ -71,3 +75,12 @@ for lo, hi in ((0, 1), (1, 2), (2, 3), (3, 4), (4, 6), (6, 1 << 30)):
     sel = (chunks >= lo) & (chunks < hi)
     if sel.any():
         print(f"  chunks [{lo},{hi}): {int(sel.sum()):5d} waves, mean {dur[sel].mean() / 100.0:6.1f} us, share of wave time {100 * dur[sel].sum() / dur.sum():5.1f}%")
+for nc in (2, 3, 4):
+    sel = chunks == nc
+    if sel.sum() < 10:
+        continue
+    ends = (ce[sel, :nc] - t0) & 0xFFFFFFFF
+    prev = np.concatenate([st[sel, None], ends[:, :-1]], axis=1)
+    per = (ends - prev).mean(axis=0) / 100.0
+    rest = (en[sel] - ends[:, -1]).mean() / 100.0
+    print(f"  waves with {nc} chunks: mean us per chunk {[round(float(v), 1) for v in per]}, after the last chunk (merges, compositor) {rest:.1f}")

@@ -521,7 +521,7 @@ __device__ uint32_t g_tile_times[8192 * 4];
 // [6] chunks, [7] chunks sorted by the bitonic fallback, [8] buckets ranked by the whole wave, [9] records in those,
 // [10] records sorted, [11..14] gather: cycles waiting for keys, for x, y, in the tests, in the staging, [15] batches,
 // [16..19] merge stage: mask walk, key reads + network, tile threshold, band tables
-__device__ unsigned long long g_stage_cycles[24];
+__device__ unsigned long long g_stage_cycles[32];  // [20..25] sweep: blocks of the lane-per-record form, of the open-pixel form, open pixels in each, early exits, blocks offered
 #define EP_STAGE(i_)                                                 \
     {                                                                \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -540,6 +540,7 @@ __device__ unsigned long long g_stage_cycles[24];
             atomicAdd(&g_stage_cycles[10], (unsigned long long)dbg_sorted);                     \
             for (int i = 0; i < 5; ++i) atomicAdd(&g_stage_cycles[11 + i], dbg_g[i]);           \
             for (int i = 0; i < 4; ++i) atomicAdd(&g_stage_cycles[16 + i], dbg_m[i]);           \
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_stage_cycles[20 + i], dbg_s[i]);           \
         }                                                                                       \
         if (lane == 0 && blockIdx.x < 8192u) {                                                  \
             g_tile_times[blockIdx.x * 4 + 0] = (uint32_t)tile | (slice_no << 24);               \
@@ -783,6 +784,26 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
     composite_and_store<10>(g, rp, ndc, kz, ki, xi, yi, xf, yf, reinterpret_cast<const float*>(recs), out);
 }
 
+// Hit masks of four pixels against the 64 records held one per lane: h[i] = ballot(d[i] < r2), then lanes L .. L+3 of
+// (lo, hi) receive the two halves of h[0] .. h[3].  Written as two assembly blocks because a VALU instruction that reads
+// a scalar register needs two other instructions between itself and the VALU instruction that wrote the register, a
+// distance the compiler keeps for its own instructions but not for the operands of inline assembly: here every lane
+// write sits at least three instructions behind its compare by construction.
+__device__ __forceinline__ void hit_masks4(const int L, float d0, float d1, float d2, float d3, float r2, uint32_t& lo,
+                                           uint32_t& hi) {
+    unsigned long long h0, h1, h2, h3;
+    asm("v_cmp_gt_f32_e64 %0, %4, %5\n\tv_cmp_gt_f32_e64 %1, %4, %6\n\tv_cmp_gt_f32_e64 %2, %4, %7\n\tv_cmp_gt_f32_e64 %3, %4, %8"
+        : "=&s"(h0), "=&s"(h1), "=&s"(h2), "=&s"(h3)
+        : "s"(r2), "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+    asm("v_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\t"
+        "v_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+        "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\t"
+        "v_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)h0), "s"((uint32_t)(h0 >> 32)), "s"((uint32_t)h1), "s"((uint32_t)(h1 >> 32)), "s"((uint32_t)h2),
+          "s"((uint32_t)(h2 >> 32)), "s"((uint32_t)h3), "s"((uint32_t)(h3 >> 32)), "n"(L), "n"(L + 1), "n"(L + 2), "n"(L + 3));
+}
+
 // Value of lane K of the caller's row of 16 lanes.  The compiler folds the move into the instruction that uses it.
 template <int K>
 __device__ __forceinline__ float row_bcast(float v) {
@@ -857,7 +878,10 @@ __device__ __forceinline__ void merge_network_desc(u64 (&kl)[EP_K]) {
     ce_desc(kl, 18, 19);
 }
 
-template <int C, int NB, int WPE, int PIXMAJ = 24, int STOP = 0>
+#ifndef EP_PIXMAJ
+#define EP_PIXMAJ 16
+#endif
+template <int C, int NB, int WPE, int PIXMAJ = EP_PIXMAJ, int STOP = 0>
 __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_raster_params rp,
                                                     const egoprior_point* __restrict__ ndc,
                                                     const uint32_t* __restrict__ tile_start,
@@ -935,7 +959,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     const uint32_t tt_records = end - pos;
     unsigned long long stage_cyc[5] = {0, 0, 0, 0, 0}, stage_t = tt0;
     uint32_t dbg_bitonic = 0, dbg_wave_buckets = 0, dbg_wave_records = 0, dbg_sorted = 0;
-    unsigned long long dbg_g[5] = {0, 0, 0, 0, 0}, dbg_m[4] = {0, 0, 0, 0};
+    unsigned long long dbg_g[5] = {0, 0, 0, 0, 0}, dbg_m[4] = {0, 0, 0, 0}, dbg_s[6] = {0, 0, 0, 0, 0, 0};
 #endif
 
     // Per-record threshold tables (rebuilt after every merge, read while the next chunk is gathered; they live in `aux`,
@@ -1371,6 +1395,12 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         int n_blocks = 0;  // blocks of 64 records that the sweep has offered to the pixels
         for (int j0 = 0; j0 < m_sweep; j0 += 64) {
             const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
+#ifdef EP_TILE_TIMES
+            if (j0 == 0) dbg_s[5] += (unsigned long long)((m_sweep + 63) / 64);
+            if (act == 0ull) dbg_s[4] += 1;
+            else if (PIXMAJ && __popcll(act) <= PIXMAJ) { dbg_s[1] += 1; dbg_s[2] += (unsigned long long)__popcll(act); }
+            else { dbg_s[0] += 1; dbg_s[3] += (unsigned long long)__popcll(act); }
+#endif
             if (act == 0ull) break;  // every pixel already holds its K nearest of this chunk
             // Offer records j0 .. j0+63 to every pixel.  Slots past m hold infinite coordinates (written by the sort
             // stage), which never hit.
@@ -1401,38 +1431,36 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
                     hm_hi = (lane == p2) ? (uint32_t)(hit2 >> 32) : hm_hi;
                 }
             } else {
-                // Sixteen records at a time sit one per lane in every row of 16 lanes; a record's coordinates reach the
-                // other lanes of the row as the broadcast operand of the subtraction itself (DPP row broadcast), so the
-                // inner loop reads no LDS at all.  Two records share each packed multiply / add / subtract of r2.  d2 < r2
-                // exactly when d2 - r2 is negative (the difference of two floats is zero only if they are equal; record
-                // coordinates are never NaN with the sign bit set): its sign bit is shifted into the mask.
+                // Every lane holds one record of the block.  The squared distance splits into a column term and a row
+                // term, (x - xf[c])^2 and (y - yf[r])^2, eight of each per record and rounded exactly as in the direct
+                // evaluation; a pixel's test is then one addition and one compare whose wave-wide result is that pixel's
+                // hit mask over the 64 records, which two lane writes drop into the pixel's lane.
+                const float2v rxy = *reinterpret_cast<const float2v*>(&S[j0 + lane].z);
+                float2v dx2[4];
+                float dy2[8];
 #pragma unroll
-                for (int h = 1; h >= 0; --h) {  // records go in last to first, 32 per mask word
-                    uint32_t bits = 0u;
-                    float2v r2v;
-                    r2v.x = r2;
-                    r2v.y = r2;
+                for (int c = 0; c < 4; ++c) {
+                    float2v d;
+                    d.x = rxy.x - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), 2 * c));
+                    d.y = rxy.x - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), 2 * c + 1));
+                    dx2[c] = d * d;
+                }
 #pragma unroll
-                    for (int g16 = 1; g16 >= 0; --g16) {
-                        const float2v rxy = *reinterpret_cast<const float2v*>(&S[j0 + h * 32 + g16 * 16 + (lane & 15)].z);
-#define EP_PAIR(A_)                                                                                \
-    {                                                                                              \
-        float2v dx, dy;                                                                            \
-        dx.x = row_bcast<A_>(rxy.x) - xf;                                                          \
-        dx.y = row_bcast<A_ + 1>(rxy.x) - xf;                                                      \
-        dy.x = row_bcast<A_>(rxy.y) - yf;                                                          \
-        dy.y = row_bcast<A_ + 1>(rxy.y) - yf;                                                      \
-        const float2v tt = (dx * dx + dy * dy) - r2v;                                              \
-        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tt.y), 31);                         \
-        bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(tt.x), 31);                         \
-    }
-                        EP_PAIR(14) EP_PAIR(12) EP_PAIR(10) EP_PAIR(8) EP_PAIR(6) EP_PAIR(4) EP_PAIR(2) EP_PAIR(0)
-#undef EP_PAIR
-                    }
-                    if (h == 0)
-                        hm_lo = bits;
-                    else
-                        hm_hi = bits;
+                for (int r = 0; r < 8; ++r) {
+                    const float d = rxy.y - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), 8 * r));
+                    dy2[r] = d * d;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    // a row of pixels is skipped when none of them is open or when no record of the block comes within
+                    // the radius of the row (the row term alone is already a lower bound on the squared distance)
+                    if (((act >> (8 * r)) & 0xFFull) == 0ull || __ballot(dy2[r] < r2) == 0ull) continue;
+                    float2v rowv;
+                    rowv.x = dy2[r];
+                    rowv.y = dy2[r];
+                    const float2v a = dx2[0] + rowv, b = dx2[1] + rowv, c = dx2[2] + rowv, d = dx2[3] + rowv;
+                    hit_masks4(r * 8, a.x, a.y, b.x, b.y, r2, hm_lo, hm_hi);  // L must fold to a constant: unrolled
+                    hit_masks4(r * 8 + 4, c.x, c.y, d.x, d.y, r2, hm_lo, hm_hi);
                 }
             }
             // Hits beyond a pixel's first K are harmless (only the first K set bits of its masks are ever read), and in the
@@ -1903,7 +1931,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
 #ifdef EP_TILE_TIMES
 #define EP_PROBE_CASE(v_, stop_)                                                                                  \
     case v_:                                                                                                       \
-        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, 24, stop_>), dim3(n_tiles + w.slices.max_slots),    \
+        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, EP_PIXMAJ, stop_>), dim3(n_tiles + w.slices.max_slots),    \
                   dim3(64), 0, s, g, *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a,  \
                   d_flags_b, w.slices, out);                                                                         \
         break;
@@ -2069,10 +2097,10 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
 }
 
 #ifdef EP_TILE_TIMES
-extern "C" int egoprior_debug_stage_cycles(unsigned long long* host24, int reset) {
-    if (hipMemcpyFromSymbol(host24, HIP_SYMBOL(ep::g_stage_cycles), 24 * sizeof(unsigned long long)) != hipSuccess) return -3;
+extern "C" int egoprior_debug_stage_cycles(unsigned long long* host32, int reset) {
+    if (hipMemcpyFromSymbol(host32, HIP_SYMBOL(ep::g_stage_cycles), 32 * sizeof(unsigned long long)) != hipSuccess) return -3;
     if (reset) {
-        unsigned long long z[24] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_stage_cycles), z, sizeof(z)) != hipSuccess) return -3;
     }
     return 0;

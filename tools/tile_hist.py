@@ -53,7 +53,7 @@ print(f"render_frame: {ev0.elapsed_time(ev1) / 3:.2f} ms")
 if "tiletimes" in str(_lib.LIB_PATH):
     import ctypes as C
     D = C.CDLL(str(_lib.LIB_PATH))
-    cbuf = (C.c_uint64 * 24)()
+    cbuf = (C.c_uint64 * 32)()
     D.egoprior_debug_stage_cycles(cbuf, 1)
     E.render_frame(cam, rp, bg)
     torch.cuda.synchronize()

@@ -32,7 +32,7 @@ rp = eng.make_raster_params(ps, He, We, rotate_cw=True)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
 cs = C.CDLL(str(_lib.LIB_PATH)).egoprior_debug_stage_cycles
-cbuf = (C.c_uint64 * 24)()
+cbuf = (C.c_uint64 * 32)()
 cs(cbuf, 1)
 E.render_frame(cam, rp, bg)
 torch.cuda.synchronize()
@@ -45,6 +45,8 @@ print("wave cycles by stage (all waves): " + ", ".join(
 print(f"chunks {c[6]}, of which bitonic {c[7]}; buckets ranked by the wave {c[8]} holding {c[9]} records; records sorted {c[10]}")
 print(f"gather: {c[15]} batches; cycles waiting for keys {c[11]:.4g}, for x, y {c[12]:.4g}, tests {c[13]:.4g}")
 print(f"merge stage: mask walk {c[16]:.4g}, key reads + network {c[17]:.4g}, tile threshold {c[18]:.4g}, band tables {c[19]:.4g}")
+print(f"sweep: {c[25]} blocks offered; lane-per-record form {c[20]} blocks ({c[23] / max(c[20], 1):.1f} open pixels each), "
+      f"open-pixel form {c[21]} blocks ({c[22] / max(c[21], 1):.1f} open pixels each), early exits {c[24]}")
 n_tiles = ((He + 7) // 8) * ((We + 7) // 8)
 buf = (C.c_uint32 * (4 * n_tiles))()
 assert dbg(buf, 4 * n_tiles) == 0

@@ -58,6 +58,22 @@ __global__ void __launch_bounds__(256) k_bench(unsigned long long* out, float se
         } else if (KIND == 10) {  // v_sub_u32 / v_add_u32 / v_and / v_bfe mix
             REP8(asm volatile("v_add_u32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_lshlrev_b32 %2, 1, %3\n v_xor_b32 %3, %3, %0"
                               : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));)
+        } else if (KIND == 11) {  // v_cmp_gt_f32 into SGPR pairs
+            REP8(asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1\n v_cmp_gt_f32_e64 s[22:23], %1, %2\n v_cmp_gt_f32_e64 s[24:25], %2, %3\n v_cmp_gt_f32_e64 s[26:27], %3, %0"
+                              : : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        } else if (KIND == 12) {  // v_writelane_b32 from SGPRs, immediate lane
+            REP8(asm volatile("v_writelane_b32 %0, s20, 3\n v_writelane_b32 %1, s21, 17\n v_writelane_b32 %2, s22, 40\n v_writelane_b32 %3, s23, 63"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : : );)
+        } else if (KIND == 13) {  // hit test of two pixels against 64 records held one per lane: packed add, two compares, four lane writes
+            REP8(asm volatile("v_pk_add_f32 %4, %5, %6\n v_cmp_gt_f32_e64 s[20:21], %7, %8\n v_cmp_gt_f32_e64 s[22:23], %8, %7\n"
+                              "v_writelane_b32 %0, s20, 3\n v_writelane_b32 %1, s21, 3\n v_writelane_b32 %0, s22, 4\n v_writelane_b32 %1, s23, 4"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(p0) : "v"(p1), "v"(p2), "v"(a7), "v"(a6) : "s20", "s21", "s22", "s23");)
+        } else if (KIND == 14) {  // hit test of two records against the 64 pixels held one per lane: four DPP subtractions, four packed operations, two alignbits
+            REP8(asm volatile("v_sub_f32_dpp %4, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_sub_f32_dpp %5, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                              "v_sub_f32_dpp %6, %10, %11 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_sub_f32_dpp %7, %10, %11 row_newbcast:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                              "v_pk_mul_f32 %1, %1, %1\n v_pk_mul_f32 %2, %2, %2\n v_pk_add_f32 %1, %1, %2\n v_pk_add_f32 %1, %1, %3\n"
+                              "v_alignbit_b32 %0, %0, %4, 31\n v_alignbit_b32 %0, %0, %5, 31"
+                              : "+v"(u0), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(a4), "v"(a5), "v"(a6), "v"(a7));)
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -99,6 +115,10 @@ int main() {
     run<5>("v_cmp_lt_u64", 32, d_out);
     run<6>("v_lshl_add_u64", 32, d_out);
     run<3>("v_cmp_lt_u64 + 4 v_cndmask (sgpr)", 40, d_out);
+    run<11>("v_cmp_gt_f32 (sgpr pair)", 32, d_out);
+    run<12>("v_writelane_b32", 32, d_out);
+    run<13>("2 pixels x 64 records (7 inst)", 56, d_out);
+    run<14>("2 records x 64 pixels (10 inst)", 80, d_out);
     hipFree(d_out);
     return 0;
 }

@@ -1393,6 +1393,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
         m_sweep = (int)uniform_u32((uint32_t)m_sweep);
         int n_blocks = 0;  // blocks of 64 records that the sweep has offered to the pixels
+        // the tile's eight pixel columns and rows as wave-uniform values (lanes 0..7 hold the columns, every eighth lane a row)
+        float xcol[8], yrow[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xcol[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), i));
+            yrow[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), 8 * i));
+        }
         for (int j0 = 0; j0 < m_sweep; j0 += 64) {
             const u64 act = __ballot(cnt < K && j0 < jlim);  // pixels that can still take a record of this block
 #ifdef EP_TILE_TIMES
@@ -1441,13 +1448,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float2v d;
-                    d.x = rxy.x - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), 2 * c));
-                    d.y = rxy.x - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xf), 2 * c + 1));
+                    d.x = rxy.x - xcol[2 * c];
+                    d.y = rxy.x - xcol[2 * c + 1];
                     dx2[c] = d * d;
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float d = rxy.y - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yf), 8 * r));
+                    const float d = rxy.y - yrow[r];
                     dy2[r] = d * d;
                 }
 #pragma unroll

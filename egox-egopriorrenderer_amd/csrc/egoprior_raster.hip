@@ -644,6 +644,24 @@ __device__ __forceinline__ void fill_color_lut(float* lut, const egoprior_raster
     __syncthreads();
 }
 
+// a / b for a divisor that is the same for every fragment.  This is the instruction sequence of the compiler's own
+// float division (reciprocal refined once, quotient refined twice with exact FMA residuals) without its range scaling
+// and special-case fix-up, and with the reciprocal part computed once: the same bits whenever a, b and a / b are
+// normal numbers or a is zero.  Here b is the squared radius and 0 <= a < b; a quotient too small to be normal only
+// ever enters 1 - a / b, which is 1 for anything below 2^-25.
+__device__ __forceinline__ float refined_rcp(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_by_uniform(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+}
+
 template <int GB>
 __device__ __forceinline__ void composite_and_store(const RasterGeom& g, const egoprior_raster_params& rp,
                                                     const egoprior_point* __restrict__ ndc,
@@ -652,6 +670,7 @@ __device__ __forceinline__ void composite_and_store(const RasterGeom& g, const e
     const int K = rp.K;
     const size_t pix = (size_t)yi * (size_t)g.W + (size_t)xi;
     float cum = 1.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    const float rcp_r2w = refined_rcp(rp.radius_sq_w);
     constexpr int G = 5;  // fragments per skip group
     static_assert(EP_K % GB == 0 && GB % G == 0, "batch and group sizes");
 #pragma unroll
@@ -678,20 +697,19 @@ __device__ __forceinline__ void composite_and_store(const RasterGeom& g, const e
                 for (int k = 0; k < G; ++k) {
                     const egoprior_point q = p[gq * G + k];
                     const bool filled = (h + k < K) && (ki[h + k] != 0xFFFFFFFFu);
-                    float d2 = -1.0f;
-                    if (filled) {
-                        const float dx = q.x - xf;
-                        const float dy = q.y - yf;
-                        d2 = dx * dx + dy * dy;
-                        const float fr = lut[q.rgba & 0xFFu], fg = lut[(q.rgba >> 8) & 0xFFu],
-                                    fb = lut[(q.rgba >> 16) & 0xFFu];
-                        const float alpha = 1.0f - d2 / rp.radius_sq_w;
-                        const float wgt = cum * alpha;
-                        cr += wgt * fr;
-                        cg += wgt * fg;
-                        cb += wgt * fb;
-                        cum = cum * (1.0f - alpha);
-                    }
+                    // an empty slot goes through the same arithmetic on record 0 with alpha = 0, which leaves the sums as
+                    // they are (all terms are >= +0): a select instead of a divergent branch per fragment
+                    const float dx = q.x - xf;
+                    const float dy = q.y - yf;
+                    const float dd = dx * dx + dy * dy;
+                    const float d2 = filled ? dd : -1.0f;
+                    const float fr = lut[q.rgba & 0xFFu], fg = lut[(q.rgba >> 8) & 0xFFu], fb = lut[(q.rgba >> 16) & 0xFFu];
+                    const float alpha = filled ? 1.0f - div_by_uniform(dd, rp.radius_sq_w, rcp_r2w) : 0.0f;
+                    const float wgt = cum * alpha;
+                    cr += wgt * fr;
+                    cg += wgt * fg;
+                    cb += wgt * fb;
+                    cum = cum * (1.0f - alpha);
                     if (out.idx != nullptr && h + k < K) {
                         const size_t o = pix * (size_t)K + (size_t)(h + k);
                         out.idx[o] = filled ? (int32_t)ki[h + k] : -1;
@@ -938,6 +956,15 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
     u64 kl[EP_K];  // (depth bits << 32 | index), descending: position EP_K-1-a holds the a-th nearest fragment
 #pragma unroll
     for (int k = 0; k < EP_K; ++k) kl[k] = ~0ull;
+    // the pixel's K-th nearest key so far (all ones while its list is not full); K is the same for the whole launch
+    auto kth_key = [&]() -> u64 {
+        if (K == EP_K) return kl[0];
+        u64 v = ~0ull;
+#pragma unroll
+        for (int p = 0; p < EP_K; ++p)
+            if (p == EP_K - K) v = kl[p];
+        return v;
+    };
     u64 T = ~0ull;  // only keys below T can still enter some pixel's top K
     uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
     if (my_slot != EP_NO_SLOT) {  // this wave's share of the list
@@ -1372,10 +1399,7 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         // and S is sorted, so those are a prefix S[0, jlim) found by binary search.
         int jlim = m;
         if (chunk_no > 0) {
-            u64 mine = ~0ull;
-#pragma unroll
-            for (int p = 0; p < EP_K; ++p)
-                if (p == EP_K - K) mine = kl[p];
+            const u64 mine = kth_key();
             int lo = 0, hi = m;  // first position whose key is >= mine
             while (__ballot(lo < hi) != 0ull) {
                 if (lo < hi) {
@@ -1550,25 +1574,13 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(RasterGeom g, egoprior_
         ++chunk_no;
         EP_MSTAGE(1)
         if (pos < end) {
-            u64 mine = 0ull;  // outside pixels never raise the threshold
-            if (inside) {
-                mine = ~0ull;
-#pragma unroll
-                for (int p = 0; p < EP_K; ++p)
-                    if (p == EP_K - K) mine = kl[p];
-            }
+            const u64 mine = inside ? kth_key() : 0ull;  // outside pixels never raise the threshold
             T = wave_max_u64(mine);
         }
         EP_MSTAGE(2)
         if (pos < end && chunk_no > 1) {
             // threshold tables for the next gather: row / column maxima of the K-th keys, then every band of them
-            u64 mine = 0ull;
-            if (inside) {
-                mine = ~0ull;
-#pragma unroll
-                for (int p = 0; p < EP_K; ++p)
-                    if (p == EP_K - K) mine = kl[p];
-            }
+            const u64 mine = inside ? kth_key() : 0ull;
             u64 rmax = mine, cmax = mine;
 #pragma unroll
             for (int d = 1; d < 8; d <<= 1) {

@@ -177,11 +177,18 @@ __global__ void __launch_bounds__(256, 8) k_project_count(egoprior_camera cam, R
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
         const int64_t lim = (base + EP_BIN_PPB < n_round) ? base + EP_BIN_PPB : n_round;
+        // the record of the next trip is requested before this trip's arithmetic (indices past the end read the last record)
+        auto fetch = [&](int64_t i) -> egoprior_point {
+            i = i < n ? i : n - 1;
+            return (i < na) ? a[i] : b[i - na];
+        };
+        egoprior_point nxt = fetch(base + threadIdx.x);
         for (int64_t i = base + threadIdx.x; i < lim; i += blockDim.x) {
             const bool live = i < n;
             float ox = 0.f, oy = 0.f, oz = -1.f;
+            const egoprior_point p = nxt;
+            if (i + blockDim.x < lim) nxt = fetch(i + blockDim.x);
             if (live) {
-                const egoprior_point p = (i < na) ? a[i] : b[i - na];
                 if (PROJECT) {
                     project_point(cam, p.x, p.y, p.z, ox, oy, oz);
                     // The render-entry filters of the reference (finite coordinates, |p| < 1e6 with the float32 norm
@@ -216,15 +223,29 @@ __global__ void __launch_bounds__(256, 8) k_project_count(egoprior_camera cam, R
         // wg_piece (optional): the value the atomic returns is where this workgroup's entries start inside the tile's list;
         // k_tile_fill_pieces, which sends the same points through the same workgroups, picks it up from there
         uint32_t* const mine = (wg_piece != nullptr) ? wg_piece + (size_t)blockIdx.x * (size_t)n_tiles : nullptr;
-        for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
-            const uint32_t c = hist[w];
-            if ((c & 0xFFFFu) != 0u) {
-                const uint32_t b = atomicAdd(&tile_count[2 * w], c & 0xFFFFu);
-                if (mine != nullptr) mine[2 * w] = b;
+        // four words per thread and trip: the returning atomics of a trip are all issued before the first result is used
+        for (int w0 = threadIdx.x; w0 < n_words; w0 += 4 * blockDim.x) {
+            uint32_t c[4], b0[4], b1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = w0 + j * (int)blockDim.x;
+                c[j] = (w < n_words) ? hist[w] : 0u;
             }
-            if ((c >> 16) != 0u) {
-                const uint32_t b = atomicAdd(&tile_count[2 * w + 1], c >> 16);
-                if (mine != nullptr) mine[2 * w + 1] = b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = w0 + j * (int)blockDim.x;
+                b0[j] = 0u;
+                b1[j] = 0u;
+                if ((c[j] & 0xFFFFu) != 0u) b0[j] = atomicAdd(&tile_count[2 * w], c[j] & 0xFFFFu);
+                if ((c[j] >> 16) != 0u) b1[j] = atomicAdd(&tile_count[2 * w + 1], c[j] >> 16);
+            }
+            if (mine != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int w = w0 + j * (int)blockDim.x;
+                    if ((c[j] & 0xFFFFu) != 0u) mine[2 * w] = b0[j];
+                    if ((c[j] >> 16) != 0u) mine[2 * w + 1] = b1[j];
+                }
             }
         }
     }
@@ -423,21 +444,23 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
 // The fill pass without global atomics.  The counting pass added every workgroup's per-tile counts to
 // the global counters and kept what those atomics returned (wg_piece): that is where the workgroup's entries start
 // inside each tile's list.  The same grid over the same points runs here, so a workgroup only has to hand out the slots
-// inside its own pieces, which it does with returning LDS atomics on 16-bit cursors (two per word, as in the counting
-// pass).  List order still depends on which workgroup's flush reached a counter first, the selection does not.
+// inside its own pieces, which it does with returning LDS atomics on per-tile cursors that start at the first slot of
+// the workgroup's piece.  List order still depends on which workgroup's flush reached a counter first, the selection
+// does not.
 __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const egoprior_point* __restrict__ ndc,
                                                           int64_t cap, const int32_t* __restrict__ d_n,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ wg_piece,
                                                           ListEntry* __restrict__ list, uint32_t capacity) {
-    extern __shared__ uint32_t cur[];
+    extern __shared__ uint32_t cur[];  // per tile: the next free slot of this workgroup's piece of the tile's list
     const int n_tiles = g.tiles_x * g.tiles_y;
-    const int n_words = (n_tiles + 1) >> 1;
     const int64_t n = live_count(d_n, cap);
     if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;
-    for (int w = threadIdx.x; w < n_words; w += 256) cur[w] = 0u;
-    __syncthreads();
+    // One coalesced pass over the two tables instead of two dependent global loads per run and tile inside the loop below
+    // (entries of tiles this workgroup never counted a point for are stale; nothing reads them).
     const uint32_t* const mine = wg_piece + (size_t)blockIdx.x * (size_t)n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) cur[t] = tile_start[t] + mine[t];
+    __syncthreads();
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     const int lane = lane_id();
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
@@ -460,11 +483,7 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
                 for (int tx = tx0; tx <= tx1; ++tx) {
                     const int t = ty * g.tiles_x + tx;
                     uint32_t slot0 = 0u;
-                    if (r.head) {
-                        const uint32_t sh = (uint32_t)(t & 1) * 16u;
-                        const uint32_t pos = (atomicAdd(&cur[t >> 1], r.len << sh) >> sh) & 0xFFFFu;
-                        slot0 = tile_start[t] + mine[t] + pos;
-                    }
+                    if (r.head) slot0 = atomicAdd(&cur[t], r.len);
                     // all lanes of a run walk the same rectangle, so the head is in this iteration too
                     const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
                     if (slot < capacity) list[slot] = entry;
@@ -1779,9 +1798,13 @@ int bin_grid(int64_t n) {
     return (int)b;
 }
 
-// bytes of the pieces table for n points (0 when the counting pass cannot aggregate in LDS for this size)
+// the fill pass that works from the pieces table keeps one 32-bit cursor per tile in LDS
+size_t fill_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)n_tiles; }
+
+// bytes of the pieces table for n points (0 when the counting pass cannot aggregate in LDS for this size, or the fill
+// pass cannot hold its cursors there)
 size_t pieces_bytes(int n_tiles, int64_t n) {
-    if (!lds_agg_possible(n_tiles, n)) return 0;
+    if (!lds_agg_possible(n_tiles, n) || fill_lds_bytes(n_tiles) > 64 * 1024) return 0;
     return align_up((size_t)bin_grid(n) * (size_t)n_tiles * sizeof(uint32_t), 256);
 }
 
@@ -1925,7 +1948,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
                   w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
     const bool lds = tn.bin_lds != 0 && lds_agg_possible(n_tiles, n);
     if (lds && w.pieces != nullptr)
-        EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), bin_lds_bytes(n_tiles), s, g,
+        EP_LAUNCH("k_tile_fill_pieces", ep::k_tile_fill_pieces, dim3(bin_grid(n)), dim3(256), fill_lds_bytes(n_tiles), s, g,
                   d_ndc, n, d_n, w.tile_start, w.pieces, w.list, (uint32_t)w.capacity);
     else
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,

@@ -1642,7 +1642,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         u64* const mine_p = sp.partial + (size_t)my_slot * (EP_K * 64) + lane;
 #pragma unroll
         for (int k = 0; k < EP_K; ++k) mine_p[k * 64] = kl[k];
-        __threadfence();  // the lists are visible to the device before the arrival is counted
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the lists are visible to the device before the arrival is counted
         uint32_t before = 0u;
         if (lane == 0) before = atomicAdd(&sp.done[tile], 1u);
         before = uniform_u32(before);
@@ -1651,7 +1651,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             EP_SPAN_END()
             return;
         }
-        __threadfence();  // and the others' lists are read only after their arrivals have been seen
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // and the others' lists are read only after their arrivals have been seen
         const uint32_t first = sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
             if (first + o == my_slot) continue;

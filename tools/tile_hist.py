@@ -74,3 +74,8 @@ if "tiletimes" in str(_lib.LIB_PATH):
     for o in np.argsort(-cyc)[:10]:
         print(f"  tile {tile[o]:5d} records {rec[o]:7d} chunks {chunks[o]:4d} cycles {cyc[o]:9d} "
               f"({cyc[o] / max(chunks[o], 1):7.0f} per chunk, {rec[o] / max(chunks[o], 1):6.0f} records per chunk)")
+_lib.profile_begin()
+for _ in range(3):
+    E.render_frame(cam, rp, bg)
+torch.cuda.synchronize()
+print("per kernel (us): " + ", ".join(f"{nm} {1e3 * ms / calls:.0f}" for nm, (ms, calls) in _lib.profile_end().items()))

@@ -1638,20 +1638,24 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     }
 #endif
     if (my_slot != EP_NO_SLOT) {
-        // Hand this slice's lists over; the wave that finds all the others already there merges them and goes on.
+        // Hand this slice's lists over; the wave that finds all the others already there merges them and goes on.  The
+        // GPU's eight L2 caches are not coherent with each other, and a device-scope release fence writes a whole L2 back:
+        // the lists are stored write-through instead (agent-scope relaxed atomic stores), the wave waits for its stores
+        // to drain and only then counts itself in; the merging wave reads every byte of the other slices' lists with
+        // agent-scope loads, which pass its own L1.  No fence on either side.
         u64* const mine_p = sp.partial + (size_t)my_slot * (EP_K * 64) + lane;
 #pragma unroll
-        for (int k = 0; k < EP_K; ++k) mine_p[k * 64] = kl[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the lists are visible to the device before the arrival is counted
+        for (int k = 0; k < EP_K; ++k) __hip_atomic_store(&mine_p[k * 64], kl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t before = 0u;
-        if (lane == 0) before = atomicAdd(&sp.done[tile], 1u);
+        if (lane == 0) before = __hip_atomic_fetch_add(&sp.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         before = uniform_u32(before);
         if (before != n_slices - 1u) {
             EP_DIAG_FLUSH()
             EP_SPAN_END()
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // and the others' lists are read only after their arrivals have been seen
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below behind the count)
         const uint32_t first = sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
             if (first + o == my_slot) continue;
@@ -1661,7 +1665,8 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             for (int p0 = 0; p0 < EP_K; p0 += 10) {
 #pragma unroll
                 for (int p = p0; p < p0 + 10; ++p) {
-                    const u64 kb = __builtin_nontemporal_load(&theirs[(EP_K - 1 - p) * 64]), ka = kl[p];
+                    const u64 kb = __hip_atomic_load(&theirs[(EP_K - 1 - p) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 ka = kl[p];
                     kl[p] = kb < ka ? kb : ka;
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -86,6 +86,10 @@ Opt g_opts[] = {
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
     {"slices", 1},         // 1: tiles with very long lists are split over several waves, 0: one wave per tile always
     {"scan_threads", 256},  // workgroup size of the tile scan: 256 or 1024
+    {"tail_slots", 0},      // > 0: the number of splat waves the GPU holds at once (3072 on MI355X: 256 compute units x
+                            // 12); when the tiles with real work would leave the last round of a launch mostly empty,
+                            // the tiles of that round are cut into three slices each.  Off by default: it shortens a
+                            // lone launch for some views and costs the tile scan more than that on average
 };
 }  // namespace
 

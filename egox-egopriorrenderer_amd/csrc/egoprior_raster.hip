@@ -261,15 +261,22 @@ struct SlicePlan {
     uint32_t* slot_base;   // n_tiles: first slot of a sliced tile, EP_NO_SLOT for the others
     uint32_t* done;        // n_tiles: slices of the tile that have finished (sliced tiles only)
     uint32_t* map;         // max_slots: tile | slice << 24 of every slot
-    uint32_t* total;       // 1: slots in use this launch
+    uint32_t* total;       // [0]: slots in use this launch, [1]: the tail cut of this launch (see below)
     unsigned long long* partial;  // max_slots x EP_K x 64 keys: the per-pixel lists of every slice, descending
     uint32_t max_slots;    // 0: slicing is off
+    uint32_t wave_slots;   // waves of the splat kernel the GPU holds at once; 0: no tail slicing
 };
 #define EP_SLICE_LEN 16384u
 #define EP_MAX_SLICES 64u
 #define EP_NO_SLOT 0xFFFFFFFFu
-__host__ __device__ __forceinline__ uint32_t slices_for(uint32_t count) {
-    if (count <= 2u * EP_SLICE_LEN) return 1u;
+// The tail of a launch.  When the tiles with real work (EP_TAIL_MIN entries or more) outnumber the wave slots of the GPU
+// and the last round of them would be less than three quarters full, that round would keep most of the GPU idle for the
+// duration of a whole tile.  k_tile_scan then picks a list length, the tail cut, such that the tiles from EP_TAIL_MIN
+// entries up to the cut are (about) the ones of that last round, and each of them is cut into EP_TAIL_SLICES slices.
+#define EP_TAIL_MIN 384u
+#define EP_TAIL_SLICES 3u
+__host__ __device__ __forceinline__ uint32_t slices_for(uint32_t count, uint32_t tail_cut) {
+    if (count <= 2u * EP_SLICE_LEN) return (count >= EP_TAIL_MIN && count <= tail_cut) ? EP_TAIL_SLICES : 1u;
     const uint32_t ns = (count + EP_SLICE_LEN - 1u) / EP_SLICE_LEN;
     return ns > EP_MAX_SLICES ? EP_MAX_SLICES : ns;
 }
@@ -288,12 +295,15 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t ohist[256];
-    __shared__ uint32_t want_s;
+    __shared__ uint32_t want_s, cut_s, tail_tiles_s, slot_s;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
         carry_s = 0;
         want_s = 0;
+        cut_s = 0;
+        tail_tiles_s = 0;
+        slot_s = 0;
     }
     if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
@@ -324,7 +334,7 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
             if (t0 + k < n_tiles) {
                 tile_start[t0 + k] = run;
                 tile_cursor[t0 + k] = 0u;
-                if (v[k] > 2u * EP_SLICE_LEN) want += slices_for(v[k]);
+                if (v[k] > 2u * EP_SLICE_LEN) want += slices_for(v[k], 0u);
                 atomicAdd(&ohist[255u - min(v[k] >> 4, 255u)], 1u);
             }
             run += v[k];
@@ -336,6 +346,12 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     if (tid == 0) {
         tile_start[n_tiles] = carry_s;
         if (d_status != nullptr && carry_s > capacity) *d_status = 1;  // sticky: only the caller clears it
+    }
+    // slots the heavy tiles want (known before the launch order is written, which hands the slots out)
+    if (sp.max_slots != 0u && __ballot(want != 0u) != 0ull) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) want += __shfl_xor(want, d);
+        if (lane == 0) atomicAdd(&want_s, want);
     }
     // exclusive scan of the 256 length classes (4 waves), then the launch order
     uint32_t c = 0, incl = 0;
@@ -356,59 +372,56 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
         ohist[tid] = woff + incl - c;
     }
     __syncthreads();
+    // The tail cut (classes are 16 entries wide, class index 255 - length / 16: ohist[k] = tiles longer than class k's).
+    if (tid < 256 && sp.max_slots != 0u && sp.wave_slots != 0u) {
+        constexpr uint32_t k_min = 255u - EP_TAIL_MIN / 16u;  // the class of the shortest tiles that count as work
+        const uint32_t n_long = ohist[k_min + 1u];
+        const uint32_t rounds = n_long / sp.wave_slots;
+        const uint32_t first_of_tail = rounds * sp.wave_slots;  // rank, longest first, of the first tile of the last round
+        const uint32_t tail = n_long - first_of_tail;
+        if (rounds != 0u && tail != 0u && 4u * tail <= 3u * sp.wave_slots) {
+            // the class that holds the tile of that rank (its longer members are cut too); not class 0, which holds every
+            // list of 4080 entries or more: the number of tail tiles must be exact, it decides whether the slots suffice
+            const uint32_t mine_k = (uint32_t)tid;
+            const bool here = mine_k >= 1u && mine_k <= k_min && ohist[mine_k] <= first_of_tail &&
+                              first_of_tail < ohist[mine_k + 1u];
+            if (here) {
+                cut_s = ((255u - mine_k) << 4) + 15u;
+                tail_tiles_s = n_long - ohist[mine_k];
+            }
+        }
+    }
+    __syncthreads();
+    // heavy tiles all or nothing; the tail slices come on top when the slots allow
+    uint32_t want_all = (sp.max_slots != 0u) ? want_s : 0u, cut = cut_s;
+    if (want_all > sp.max_slots) {
+        want_all = 0u;
+        cut = 0u;
+    } else if (cut != 0u && want_all + EP_TAIL_SLICES * tail_tiles_s <= sp.max_slots) {
+        want_all += EP_TAIL_SLICES * tail_tiles_s;
+    } else {
+        cut = 0u;
+    }
+    const bool slicing = want_all != 0u;
+    if (tid == 0 && sp.max_slots != 0u) {
+        sp.total[0] = want_all;  // (the per-tile slot words are only read when this says that there are slices)
+        sp.total[1] = cut;
+    }
+    // The launch order, and with it the slots of the sliced tiles: which slot a slice gets does not matter, so they are
+    // handed out by a counter as the tiles come by.
     for (int t = tid; t < n_tiles; t += NT) {
         const uint32_t v = tile_count[t];
         tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
-    }
-    if (sp.max_slots == 0u) return;
-    if (__ballot(want != 0u) != 0ull) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) want += __shfl_xor(want, d);
-        if (lane == 0) atomicAdd(&want_s, want);
-    }
-    __syncthreads();
-    const uint32_t want_all = want_s;
-    const bool slicing = want_all != 0u && want_all <= sp.max_slots;  // all or nothing: the slots are handed out by a scan
-    if (tid == 0) *sp.total = slicing ? want_all : 0u;
-    if (!slicing) return;  // (the per-tile slot words are only read when the total says that there are slices)
-    for (int t = tid; t < n_tiles; t += NT) sp.slot_base[t] = EP_NO_SLOT;
-    // slots of the sliced tiles: an exclusive scan of their slice counts, in tile order
-    __syncthreads();
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n_tiles; base += NT * PT) {
-        const int t0 = base + tid * PT;
-        uint32_t v[PT];
-        uint32_t sum = 0;
-#pragma unroll
-        for (int k = 0; k < PT; ++k) {
-            const uint32_t ns = (t0 + k < n_tiles) ? slices_for(tile_count[t0 + k]) : 1u;
-            v[k] = ns > 1u ? ns : 0u;
-            sum += v[k];
-        }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wave_sums[wid] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w2 = 0; w2 < wid; ++w2) woff += wave_sums[w2];
-        uint32_t run = carry_s + woff + incl - sum;
-#pragma unroll
-        for (int k = 0; k < PT; ++k) {
-            if (v[k] != 0u) {
-                sp.slot_base[t0 + k] = run;
-                sp.done[t0 + k] = 0u;
-                for (uint32_t q = 0; q < v[k]; ++q) sp.map[run + q] = (uint32_t)(t0 + k) | (q << 24);
+        if (slicing) {
+            const uint32_t ns = (want_s > sp.max_slots) ? 1u : slices_for(v, cut);
+            uint32_t slot = EP_NO_SLOT;
+            if (ns > 1u) {
+                slot = atomicAdd(&slot_s, ns);
+                sp.done[t] = 0u;
+                for (uint32_t q = 0; q < ns && slot + q < sp.max_slots; ++q) sp.map[slot + q] = (uint32_t)t | (q << 24);
             }
-            run += v[k];
+            sp.slot_base[t] = slot;
         }
-        __syncthreads();
-        if (tid == NT - 1) carry_s = run;
-        __syncthreads();
     }
 }
 
@@ -940,19 +953,20 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
     uint32_t(*const masks)[64] = reinterpret_cast<uint32_t(*)[64]>(aux);  // row 2 b + h: records 32 h .. 32 h + 31 of block b
 
-    // The first sp.max_slots workgroups of the launch take the slices of the heavy tiles (the slots in use come first, the
-    // others leave at once); the rest take one tile each, longest list first, and leave the sliced tiles alone.
+    // The first workgroups of the launch take one tile each, longest list first, and leave the sliced tiles alone; the
+    // sp.max_slots workgroups behind them take the slices (the slots in use come first, the others leave at once).
     int tile;
     uint32_t my_slot = EP_NO_SLOT, n_slices = 1u, slice_no = 0u;
-    if (blockIdx.x < sp.max_slots) {
-        if (blockIdx.x >= *sp.total) return;
-        const uint32_t packed = sp.map[blockIdx.x];
+    const uint32_t n_tiles_all = (uint32_t)(g.tiles_x * g.tiles_y);
+    if (blockIdx.x >= n_tiles_all) {
+        my_slot = blockIdx.x - n_tiles_all;
+        if (my_slot >= sp.total[0]) return;
+        const uint32_t packed = sp.map[my_slot];
         tile = (int)(packed & 0xFFFFFFu);
         slice_no = packed >> 24;
-        my_slot = blockIdx.x;
     } else {
-        tile = (int)tile_order[blockIdx.x - sp.max_slots];
-        if (sp.max_slots != 0u && *sp.total != 0u && sp.slot_base[tile] != EP_NO_SLOT) return;
+        tile = (int)tile_order[blockIdx.x];
+        if (sp.max_slots != 0u && sp.total[0] != 0u && sp.slot_base[tile] != EP_NO_SLOT) return;
     }
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int lane = threadIdx.x;
@@ -989,7 +1003,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
     if (my_slot != EP_NO_SLOT) {  // this wave's share of the list
         const uint32_t count = end - pos;
-        n_slices = slices_for(count);
+        n_slices = slices_for(count, sp.total[1]);
         const uint32_t span = slice_span(count, n_slices);
         pos = min(pos + slice_no * span, end);
         end = min(pos + span, end);
@@ -1724,6 +1738,8 @@ k_splat_sweep<512, 512, 3, EP_PIXMAJ, 0>(EP_SPLAT_ARGS) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side of the C ABI for this file
 // ------------------------------------------------------------------------------------------------------------------
+#include <algorithm>
+
 #include "egoprior_host.h"
 
 namespace {
@@ -1766,7 +1782,7 @@ int check_list_size(const ep::RasterGeom& g, int64_t n) {
 // The tuning switches a call works with, read once when the call starts (egoprior_set_option may change them from
 // another thread at any time; a call in progress keeps the values it started with).
 struct Tuning {
-    int splat_variant, fill_pieces, bin_lds, slices, scan_threads;
+    int splat_variant, fill_pieces, bin_lds, slices, scan_threads, tail_slots;
 };
 Tuning read_tuning() {
     Tuning t;
@@ -1775,6 +1791,7 @@ Tuning read_tuning() {
     t.bin_lds = ep_host::option("bin_lds");
     t.slices = ep_host::option("slices");
     t.scan_threads = ep_host::option("scan_threads");
+    t.tail_slots = ep_host::option("tail_slots");
     return t;
 }
 
@@ -1797,7 +1814,13 @@ struct RasterWs {
 
 // Slots that `entries` list entries can need at most: a sliced tile has more than 2 * EP_SLICE_LEN entries and takes
 // ceil(entries of the tile / EP_SLICE_LEN) slots, fewer than 1.5 slots per EP_SLICE_LEN entries.
-uint64_t slice_slots_for(uint64_t entries) { return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2; }
+// ... plus the slices of a launch's tail: at most three quarters of the wave slots' worth of tiles, each of which holds
+// EP_TAIL_MIN entries or more.
+constexpr uint64_t kWaveSlots = 256 * 12;  // MI355X: 256 compute units, three splat waves on each of their four SIMDs
+uint64_t slice_slots_for(uint64_t entries) {
+    const uint64_t tail_tiles = std::min<uint64_t>(3 * kWaveSlots / 4, entries / EP_TAIL_MIN);
+    return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2 + EP_TAIL_SLICES * tail_tiles;
+}
 constexpr size_t kSlotBytes = (size_t)EP_K * 64 * sizeof(unsigned long long);
 size_t slice_area_bytes(int n_tiles, uint64_t entries) {
     const uint64_t slots = slice_slots_for(entries);
@@ -1862,7 +1885,7 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
     const size_t rest = bytes - off;
     uint64_t cap = rest / sizeof(ep::ListEntry);
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    r.slices = ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    r.slices = ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
     if (tn.slices != 0 && tn.splat_variant != 1) {
         // largest capacity whose lists and slice area both fit (the need grows with the capacity: bisection)
         auto need = [&](uint64_t c) { return align_up((size_t)c * sizeof(ep::ListEntry), 256) + slice_area_bytes(n_tiles, c); };
@@ -1886,6 +1909,7 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
             q += align_up(sizeof(uint32_t) * slots, 256);
             r.slices.partial = (unsigned long long*)q;
             r.slices.max_slots = (uint32_t)(slots > 0x00FFFFFFull ? 0x00FFFFFFull : slots);
+            r.slices.wave_slots = tn.tail_slots > 0 ? (uint32_t)tn.tail_slots : 0u;
         }
     }
     r.capacity = cap;
@@ -2161,7 +2185,7 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
     if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, nullptr, w, tn, s)) return e;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan<1024>, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr,
-              ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u});
+              ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u});
     EP_LAUNCH("k_copy_total", k_copy_total, dim3(1), dim3(64), 0, s, w.tile_start + n_tiles, d_entries);
     return ep_host::check_launch("count_list_entries");
 }

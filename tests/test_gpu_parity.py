@@ -395,6 +395,37 @@ def test_rasterize_heavy_tiles_are_sliced(engine, mode, splat_variant):
         assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
+def test_rasterize_tail_tiles_are_sliced(engine):
+    """Option "tail_slots": when the tiles with real work outnumber the wave slots and the last round of them would be
+    mostly empty, the tiles of that round are cut into three slices each (the hand-over of the heavy tiles, for lists of a
+    few hundred entries).  64 tiles of 600 - 1400 entries with the option at 24 "slots": two full rounds and a tail of 16.
+    Same fragments and frame as the oracle's and as with the option off."""
+    from egoprior import _lib, engine as eng
+    H = W = 64
+    ps = 2.5
+    rng = np.random.default_rng(31)
+    n = 30_000
+    xy = rng.uniform(-1.0, 1.0, (n, 2)).astype(F32)
+    xy[:, 0] *= F32(0.98)
+    z = (2.0 + xy[:, 0] * 0.5 + rng.uniform(0.0, 0.05, n)).astype(F32)  # a slanted sheet: depth order sweeps the tiles
+    ndc = np.concatenate([xy, z[:, None]], axis=1).astype(F32)
+    cols = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    r = O.radius_ndc(ps, H, W)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, H, W, 20, "scatter")
+    ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
+    rp = eng.make_raster_params(ps, H, W, K=20, colors_gt1=1)
+    packed = pack_ndc(ndc, cols, engine.device)
+    for slots in (24, 40, 0):
+        _lib.set_option("tail_slots", slots)
+        try:
+            res = engine.rasterize_composite(packed, None, rp, H, W, want_f32=True, want_fragments=True)
+        finally:
+            _lib.set_option("tail_slots", 0)
+        assert res["status"].item() == 0
+        _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+        assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+
+
 def test_sliced_tiles_with_exact_and_short_workspaces(engine):
     """A dense blob whose tiles are sliced, rendered in a workspace sized from the frame's own entry count (exact bits)
     and in one that holds only 40 % of the entries: the lists are cut, the status word says so, and nothing is read or

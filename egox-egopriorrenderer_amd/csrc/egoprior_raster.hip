@@ -266,8 +266,12 @@ struct SlicePlan {
     uint32_t max_slots;    // 0: slicing is off
     uint32_t wave_slots;   // waves of the splat kernel the GPU holds at once; 0: no tail slicing
 };
+#ifndef EP_SLICE_LEN
 #define EP_SLICE_LEN 16384u
+#endif
+#ifndef EP_MAX_SLICES
 #define EP_MAX_SLICES 64u
+#endif
 #define EP_NO_SLOT 0xFFFFFFFFu
 // The tail of a launch.  When the tiles with real work (EP_TAIL_MIN entries or more) outnumber the wave slots of the GPU
 // and the last round of them would be less than three quarters full, that round would keep most of the GPU idle for the

@@ -413,18 +413,30 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     }
     // The launch order, and with it the slots of the sliced tiles: which slot a slice gets does not matter, so they are
     // handed out by a counter as the tiles come by.
-    for (int t = tid; t < n_tiles; t += NT) {
-        const uint32_t v = tile_count[t];
-        tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
-        if (slicing) {
-            const uint32_t ns = (want_s > sp.max_slots) ? 1u : slices_for(v, cut);
-            uint32_t slot = EP_NO_SLOT;
-            if (ns > 1u) {
-                slot = atomicAdd(&slot_s, ns);
-                sp.done[t] = 0u;
-                for (uint32_t q = 0; q < ns && slot + q < sp.max_slots; ++q) sp.map[slot + q] = (uint32_t)t | (q << 24);
+    // (eight counts are requested per trip: one at a time, every trip of this single workgroup waited out a memory round trip)
+    for (int t0 = tid; t0 < n_tiles; t0 += NT * PT) {
+        uint32_t vv[PT];
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int t = t0 + k * NT;
+            vv[k] = tile_count[t < n_tiles ? t : n_tiles - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int t = t0 + k * NT;
+            if (t >= n_tiles) break;
+            const uint32_t v = vv[k];
+            tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
+            if (slicing) {
+                const uint32_t ns = (want_s > sp.max_slots) ? 1u : slices_for(v, cut);
+                uint32_t slot = EP_NO_SLOT;
+                if (ns > 1u) {
+                    slot = atomicAdd(&slot_s, ns);
+                    sp.done[t] = 0u;
+                    for (uint32_t q = 0; q < ns && slot + q < sp.max_slots; ++q) sp.map[slot + q] = (uint32_t)t | (q << 24);
+                }
+                sp.slot_base[t] = slot;
             }
-            sp.slot_base[t] = slot;
         }
     }
 }

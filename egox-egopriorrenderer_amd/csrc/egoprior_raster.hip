@@ -1672,7 +1672,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         // GPU's eight L2 caches are not coherent with each other, and a device-scope release fence writes a whole L2 back:
         // the lists are stored write-through instead (agent-scope relaxed atomic stores), the wave waits for its stores
         // to drain and only then counts itself in; the merging wave reads every byte of the other slices' lists with
-        // agent-scope loads, which pass its own L1.  No fence on either side.
+        // agent-scope loads, which pass its own L1.  No release fence; one acquire, in the merging wave only.
         u64* const mine_p = sp.partial + (size_t)my_slot * (EP_K * 64) + lane;
 #pragma unroll
         for (int k = 0; k < EP_K; ++k) __hip_atomic_store(&mine_p[k * 64], kl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1685,7 +1685,11 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             EP_SPAN_END()
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below behind the count)
+        // The merging wave alone pays an acquire (an invalidate of its compute unit's L1, nothing on the L2): the loads
+        // below pass the L1 anyway, the fence keeps them behind the count and covers placements of several workgroups on a
+        // compute unit that the write-through hand-over has not been measured for.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t first = sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
             if (first + o == my_slot) continue;

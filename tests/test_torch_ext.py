@@ -13,6 +13,8 @@ CSRC = Path(__file__).resolve().parents[1] / "egox-egopriorrenderer_amd" / "csrc
 
 
 def _ext():
+    if not (CSRC / "egoprior_torch_ext.so").exists():
+        pytest.skip("csrc/egoprior_torch_ext.so is not built (make -C egox-egopriorrenderer_amd/csrc egoprior_torch_ext.so)")
     if str(CSRC) not in sys.path:
         sys.path.insert(0, str(CSRC))
     import egoprior_torch_ext

@@ -473,22 +473,23 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
 // The fill pass without global atomics.  The counting pass added every workgroup's per-tile counts to
 // the global counters and kept what those atomics returned (wg_piece): that is where the workgroup's entries start
 // inside each tile's list.  The same grid over the same points runs here, so a workgroup only has to hand out the slots
-// inside its own pieces, which it does with returning LDS atomics on per-tile cursors that start at the first slot of
-// the workgroup's piece.  List order still depends on which workgroup's flush reached a counter first, the selection
-// does not.
+// inside its own pieces, which it does with returning LDS atomics on 16-bit cursors (two per word, as in the counting
+// pass).  List order still depends on which workgroup's flush reached a counter first, the selection does not.
 __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const egoprior_point* __restrict__ ndc,
                                                           int64_t cap, const int32_t* __restrict__ d_n,
                                                           const uint32_t* __restrict__ tile_start,
                                                           const uint32_t* __restrict__ wg_piece,
                                                           ListEntry* __restrict__ list, uint32_t capacity) {
-    extern __shared__ uint32_t cur[];  // per tile: the next free slot of this workgroup's piece of the tile's list
+    extern __shared__ uint32_t cur[];  // per tile: entries this workgroup has handed out so far, two 16-bit counters per word
     const int n_tiles = g.tiles_x * g.tiles_y;
     const int64_t n = live_count(d_n, cap);
     if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;
-    // One coalesced pass over the two tables instead of two dependent global loads per run and tile inside the loop below
-    // (entries of tiles this workgroup never counted a point for are stale; nothing reads them).
+    // (Cursors that already hold the final slot - tile_start[t] + piece[t], loaded in one coalesced pass - spare the loop
+    // its two global loads per run and tile and make the kernel 2 us faster on its own, but take 4 bytes per tile: 25 KiB
+    // at 480 x 832, which no longer fits into the 16 KiB of LDS that twelve splat waves leave of a compute unit.  With
+    // frames in flight the small footprint wins: +2 % frames/s, +4 % at 1024 x 1024.)
     const uint32_t* const mine = wg_piece + (size_t)blockIdx.x * (size_t)n_tiles;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) cur[t] = tile_start[t] + mine[t];
+    for (int w = threadIdx.x; w < (n_tiles + 1) / 2; w += 256) cur[w] = 0u;
     __syncthreads();
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     const int lane = lane_id();
@@ -512,7 +513,10 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
                 for (int tx = tx0; tx <= tx1; ++tx) {
                     const int t = ty * g.tiles_x + tx;
                     uint32_t slot0 = 0u;
-                    if (r.head) slot0 = atomicAdd(&cur[t], r.len);
+                    if (r.head) {
+                        const uint32_t sh = (uint32_t)(t & 1) * 16u;
+                        slot0 = tile_start[t] + mine[t] + ((atomicAdd(&cur[t >> 1], r.len << sh) >> sh) & 0xFFFFu);
+                    }
                     // all lanes of a run walk the same rectangle, so the head is in this iteration too
                     const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
                     if (slot < capacity) list[slot] = entry;
@@ -1869,8 +1873,8 @@ int bin_grid(int64_t n) {
     return (int)b;
 }
 
-// the fill pass that works from the pieces table keeps one 32-bit cursor per tile in LDS
-size_t fill_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)n_tiles; }
+// the fill pass that works from the pieces table keeps one 16-bit cursor per tile in LDS
+size_t fill_lds_bytes(int n_tiles) { return sizeof(uint32_t) * (size_t)((n_tiles + 1) / 2); }
 
 // bytes of the pieces table for n points (0 when the counting pass cannot aggregate in LDS for this size, or the fill
 // pass cannot hold its cursors there)

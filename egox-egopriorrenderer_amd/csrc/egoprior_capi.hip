@@ -80,8 +80,9 @@ struct Opt {
     int value;
 };
 Opt g_opts[] = {
-    {"splat_variant", 0},  // 0: sweep, 512-record chunks; 1: register insertion only; 2: sweep, 64-record chunks;
-                           // 3: sweep, 1024-record chunks; 4: sweep, 384-record chunks
+    {"splat_variant", 0},  // 0: sweep, 448-record chunks; 1: register insertion only; 2: sweep, 64-record chunks;
+                           // 3: sweep, 1024-record chunks; 4: sweep, 384-record chunks at four waves per SIMD;
+                           // 5: sweep, 512-record chunks
     {"fill_pieces", 1},    // 1: fill pass without global atomics where possible (k_tile_fill_pieces), 0: always k_tile_fill
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
     {"slices", 1},         // 1: tiles with very long lists are split over several waves, 0: one wave per tile always

@@ -928,7 +928,7 @@ constexpr int next_pow2(int v) {
 // then the EP_K smallest keys of both as a rising-then-falling sequence, which the network sorts back to descending
 // order without any scratch registers.
 // LDS per wave = C*16 (sorted records) + max(NB*4, C*8) (bucket table, hit masks and threshold tables share the space):
-// 12 KiB for C = 512, three waves per SIMD (12 per CU) in the 160 KiB of a CU.
+// 10.5 KiB for C = 448 (the default), 12 KiB for C = 512; three waves per SIMD (12 per CU) in the 160 KiB of a CU.
 // Sorts a list that rises and then falls (the element-wise minimum of a descending list and an ascending one) back into
 // descending order: a bitonic merge for a length that is not a power of two (EP_K = 16 + 4); positions 20 .. 31 would
 // hold minus infinity and never move, so the exchanges with them are left out.
@@ -1745,10 +1745,19 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(EP_SPLAT_ARGS) {
     splat_sweep_wave<C, NB, WPE, PIXMAJ, STOP>(g, rp, ndc, tile_start, tile_order, list, capacity, d_flags_a, d_flags_b, sp,
                                                out);
 }
-// The default geometry is compiled for 144 registers (the attribute counts in units of two on this target) instead of the
-// 168 that three waves per SIMD would allow: three splat waves then leave 80 registers of a SIMD free, room for a wave
-// of any other kernel of the frames in flight (they take 40 to 64), which otherwise wait for a splat wave to retire.
-// Three values spill to scratch; alone the launch is 4 % slower, with four frames in flight the frame rate is 4 % higher.
+// The default geometry, 448-entry chunks, is compiled for 144 registers (the attribute counts in units of two on this
+// target) instead of the 168 that three waves per SIMD would allow, and takes 10.5 KiB of LDS per wave.  Twelve splat waves
+// then leave a compute unit 80 registers per SIMD and 34 KiB of LDS: room for a workgroup of any other kernel of the
+// frames in flight (40 to 64 registers per wave, up to 12.5 KiB of LDS), which otherwise waits for splat waves to retire.
+// Nothing spills at seven records per lane.
+template <>
+__global__ void __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(72)))
+k_splat_sweep<448, 512, 3, EP_PIXMAJ, 0>(EP_SPLAT_ARGS) {
+    splat_sweep_wave<448, 512, 3, EP_PIXMAJ, 0>(g, rp, ndc, tile_start, tile_order, list, capacity, d_flags_a, d_flags_b, sp,
+                                                out);
+}
+// 512-entry chunks (12 KiB of LDS per wave, three values spilled) with the same register budget: option "splat_variant" 5,
+// the default before the 448-entry one.
 template <>
 __global__ void __launch_bounds__(64, 3) __attribute__((amdgpu_num_vgpr(72)))
 k_splat_sweep<512, 512, 3, EP_PIXMAJ, 0>(EP_SPLAT_ARGS) {
@@ -2046,10 +2055,13 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         case 4:  // 384-record chunks, 8.6 KiB of LDS per wave, four waves per SIMD
             EP_SWEEP(384, 512, 4);
             break;
+        case 5:  // 512-record chunks, 12 KiB of LDS per wave, three waves per SIMD (the default before the 448-record one)
+            EP_SWEEP(512, 512, 3);
+            break;
 #ifdef EP_TILE_TIMES
 #define EP_PROBE_CASE(v_, stop_)                                                                                  \
     case v_:                                                                                                       \
-        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<512, 512, 3, EP_PIXMAJ, stop_>), dim3(n_tiles + w.slices.max_slots),    \
+        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<448, 512, 3, EP_PIXMAJ, stop_>), dim3(n_tiles + w.slices.max_slots),    \
                   dim3(64), 0, s, g, *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a,  \
                   d_flags_b, w.slices, out);                                                                         \
         break;
@@ -2059,8 +2071,8 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_PROBE_CASE(14, 4)
 #undef EP_PROBE_CASE
 #endif
-        default:  // 512-record chunks, 10.6 KiB of LDS per wave, three waves per SIMD
-            EP_SWEEP(512, 512, 3);
+        default:  // 448-record chunks, 10.5 KiB of LDS per wave, three waves per SIMD
+            EP_SWEEP(448, 512, 3);
     }
 #undef EP_SWEEP
     return ep_host::check_launch("rasterize");

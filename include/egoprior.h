@@ -267,10 +267,10 @@ int egoprior_white_pixel_counts(const uint8_t* d_frames, int32_t n_frames, int32
 int egoprior_profile_begin(void);
 /* Process-wide tuning / test switches (no counterpart in the reference; the one piece of state the library keeps
  * besides the per-thread error text).  Every entry point reads them once when it starts, so a change takes effect with
- * the next call and never in the middle of one.  "splat_variant": 0 default sweep kernel (512-record chunks, three
+ * the next call and never in the middle of one.  "splat_variant": 0 default sweep kernel (448-record chunks, three
  * waves per SIMD), 1 plain register-insertion kernel, 2 sweep kernel with 64-record chunks (forces its multi-chunk path
- * on small inputs), 3 with 1024-record chunks, 4 with 384-record chunks and four waves per SIMD; every variant returns
- * the same bits.
+ * on small inputs), 3 with 1024-record chunks, 4 with 384-record chunks and four waves per SIMD, 5 with 512-record
+ * chunks; every variant returns the same bits.
  * "fill_pieces": 1 default: the tile lists are filled without global atomics where the counting pass could leave its
  * per-workgroup offsets, 0: always one reservation per run of lanes.  "bin_lds": 1 default: the tile counts are
  * aggregated per workgroup in LDS, 0: straight global atomics.  "slices": 1 default: tiles with more than 32768 list

@@ -185,11 +185,12 @@ def test_project_points(engine, size):
     assert np.array_equal(got[:, 2], ref[:, 2], equal_nan=True)
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["sweep512", "bubble", "sweep64", "sweep1024", "sweep384"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["sweep448", "bubble", "sweep64", "sweep1024", "sweep384", "sweep512"])
 def splat_variant(request):
-    """Every splat kernel variant must give the same bits: the default sweep kernel (512-record chunks), the plain
-    register-insertion kernel, the sweep kernel with 64-record chunks (forces its multi-chunk merge on these small
-    inputs), with 1024-record chunks and with 384-record chunks (not a power of two, four waves per SIMD)."""
+    """Every splat kernel variant must give the same bits: the default sweep kernel (448-record chunks: seven records per
+    lane, not a power of two), the plain register-insertion kernel, the sweep kernel with 64-record chunks (forces its
+    multi-chunk merge on these small inputs), with 1024-record chunks, with 384-record chunks (four waves per SIMD) and
+    with 512-record chunks."""
     from egoprior import _lib
     _lib.set_option("splat_variant", request.param)
     yield request.param

@@ -218,8 +218,11 @@ __device__ __forceinline__ uint32_t reliable4(const float* __restrict__ tile, in
 // Subsample factors 1 and 2: 64 x 16 samples per block, four horizontally adjacent samples per thread.  A thread pulls
 // each of its five window rows out of the LDS tile once, as 16-byte reads, and feeds all four windows from registers, so a
 // sample costs 2.5 (S=1) or 3.75 (S=2) LDS reads instead of 25.  Same arithmetic, tap by tap, as reliable_at().
+// (Built for 40 registers - the attribute counts in units of two on this target - although it would take 53: two of its
+// waves then fit into the 80 registers that three splat waves leave of a SIMD.  A few values spill and the kernel is 1 us
+// slower on its own; with frames in flight the frame rate is 3 % higher.  The same goes for k_unproject_scatter.)
 template <int S, typename DT>
-__global__ void __launch_bounds__(256) k_reliable_flags_row4(const DT* __restrict__ depth,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) k_reliable_flags_row4(const DT* __restrict__ depth,
                                                              const uint8_t* __restrict__ mask, int H, int W, int Hs,
                                                              int Ws, int select, uint8_t* __restrict__ flags) {
     constexpr int BX = 64, BY = 16;
@@ -447,7 +450,7 @@ __device__ __forceinline__ void note_color_gt1(bool any_gt1, int32_t* __restrict
 
 // flags + block offsets -> compacted records: rays * depth, c2w (float32), exo->world (float64), colour bytes
 template <typename DT>
-__global__ void __launch_bounds__(256) k_unproject_scatter(egoprior_unproject_params p, int Hs, int Ws,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(20))) k_unproject_scatter(egoprior_unproject_params p, int Hs, int Ws,
                                                            const DT* __restrict__ depth,
                                                            const float* __restrict__ rays,
                                                            const uint8_t* __restrict__ rgb,

@@ -524,18 +524,27 @@ int epc_exr_half_z_decode(const uint8_t* buf, size_t n, uint16_t* out, int32_t H
     if (!tmp) return EPC_E_NOMEM;
     uint8_t* tmp2 = tmp + max_raw + EPC_INFLATE_SLACK;
     for (size_t c = 0; c < n_chunks && rc == EPC_OK; ++c) {
+        /* the offset and the chunk size come from the file: every comparison is written so that it cannot wrap */
         const uint64_t off = rd_u64(buf + info.table + 8 * c);
-        if (off + 8 > n) { rc = EPC_E_CORRUPT; break; }
+        if (n < 8 || off > (uint64_t)n - 8) { rc = EPC_E_CORRUPT; break; }
         const int32_t y = rd_i32(buf + off), size = rd_i32(buf + off + 4);
-        if (y < info.ymin || y > info.ymax || size < 0 || off + 8 + (uint64_t)size > n) { rc = EPC_E_CORRUPT; break; }
+        /* the table lists the chunks by increasing row whatever the file's line order: chunk c starts at row ymin + c * lines
+         * (so every output row is written exactly once) */
+        if ((int64_t)y != (int64_t)info.ymin + (int64_t)c * lines || size < 0 || (uint64_t)size > (uint64_t)n - off - 8) {
+            rc = EPC_E_CORRUPT;
+            break;
+        }
         int rows = info.ymax - y + 1;
         if (rows > lines) rows = lines;
         const size_t raw_size = (size_t)rows * info.line_bytes;
         if ((size_t)size > raw_size) { rc = EPC_E_CORRUPT; break; }
         const uint8_t* data = buf + off + 8;
         const uint8_t* raw;
-        if (info.compression == 0 || (size_t)size == raw_size) { /* a chunk that does not shrink is stored as it is */
+        if ((size_t)size == raw_size) { /* uncompressed file, or a chunk that did not shrink and is stored as it is */
             raw = data;
+        } else if (info.compression == 0) { /* an uncompressed chunk holds exactly its rows: the row copy reads them all */
+            rc = EPC_E_CORRUPT;
+            break;
         } else {
             if (info.compression == 1) {
                 rc = exr_unrle(data, (size_t)size, tmp, raw_size);

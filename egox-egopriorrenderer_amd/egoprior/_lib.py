@@ -98,10 +98,8 @@ _LIB = None
 
 def build(force: bool = False) -> Path:
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force:
-        subprocess.check_call(["make", "-C", str(CSRC), "-B", "-s"])
-    else:
-        subprocess.check_call(["make", "-C", str(CSRC), "-s"])
+    targets = ["libegoprior_hip.so", "libegoprior_codec.so"]  # not the optional torch shim (`make ext`)
+    subprocess.check_call(["make", "-C", str(CSRC), "-s"] + (["-B"] if force else []) + targets)
     return LIB_PATH
 
 

@@ -426,15 +426,21 @@ def _decode_exr_half_z_py(buf: bytes) -> np.ndarray:
         n_chunks = (H + lines - 1) // lines
         offsets = struct.unpack_from(f"<{n_chunks}Q", buf, pos)
         out = np.empty((H, W), dtype=np.float16)
-        for off in offsets:
+        for c_no, off in enumerate(offsets):
+            if off > len(buf) - 8:
+                raise ValueError("chunk offset beyond the end of the file")
             y, size = struct.unpack_from("<ii", buf, off)
+            if y != ymin + c_no * lines or size < 0:  # the table lists the chunks by increasing row
+                raise ValueError("corrupt chunk header")
             rows = min(lines, ymax - y + 1)
             raw_size = rows * line_bytes
             data = buf[off + 8:off + 8 + size]
             if size > raw_size or len(data) != size:
                 raise ValueError("corrupt chunk")
-            if comp == _EXR_NO or size == raw_size:  # a chunk that does not shrink is stored as it is
+            if size == raw_size:  # uncompressed file, or a chunk that did not shrink and is stored as it is
                 raw = np.frombuffer(data, dtype=np.uint8)
+            elif comp == _EXR_NO:
+                raise ValueError("uncompressed chunk shorter than its rows")
             elif comp == _EXR_RLE:
                 raw = _exr_unfilter(_exr_unrle(data, raw_size))
             else:
@@ -508,11 +514,21 @@ def decode_png_gray(buf: bytes, out: Optional[np.ndarray] = None, native: bool =
 
 
 def _decode_png_gray_py(buf: bytes) -> np.ndarray:
+    """OSError for anything that is not a readable greyscale PNG (truncated, damaged stream, other colour types)."""
+    try:
+        return _decode_png_gray_checked(buf)
+    except (ValueError, TypeError, IndexError, struct.error, zlib.error) as e:
+        raise OSError(f"cannot read PNG data: {e}") from e
+
+
+def _decode_png_gray_checked(buf: bytes) -> np.ndarray:
     if buf[:8] != b"\x89PNG\r\n\x1a\n":
         raise ValueError("not a PNG")
     pos, idat, hdr = 8, [], None
-    while pos < len(buf):
+    while pos + 12 <= len(buf):  # (a file that ends after its last whole chunk is read as far as it goes)
         n, typ = struct.unpack(">I4s", buf[pos:pos + 8])
+        if pos + 12 + n > len(buf):
+            raise ValueError("chunk runs past the end of the file")
         body = buf[pos + 8:pos + 8 + n]
         pos += 12 + n
         if typ == b"IHDR":
@@ -521,6 +537,8 @@ def _decode_png_gray_py(buf: bytes) -> np.ndarray:
             idat.append(body)
         elif typ == b"IEND":
             break
+    if hdr is None or not idat:
+        raise ValueError("no IHDR / IDAT chunk")
     w, h, depth, ctype, _, _, interlace = hdr
     if ctype != 0 or depth not in (8, 16) or interlace != 0:
         raise ValueError(f"unsupported PNG (colour type {ctype}, depth {depth}, interlace {interlace}); install opencv")

@@ -265,6 +265,9 @@ struct SlicePlan {
     unsigned long long* partial;  // max_slots x EP_K x 64 keys: the per-pixel lists of every slice, descending
     uint32_t max_slots;    // 0: slicing is off
     uint32_t wave_slots;   // waves of the splat kernel the GPU holds at once; 0: no tail slicing
+#ifdef EP_CHECK
+    uint32_t nonce;        // differs from launch to launch (diagnostic build: seeds the hand-over checksums)
+#endif
 };
 #ifndef EP_SLICE_LEN
 #define EP_SLICE_LEN 16384u
@@ -273,6 +276,25 @@ struct SlicePlan {
 #define EP_MAX_SLICES 64u
 #endif
 #define EP_NO_SLOT 0xFFFFFFFFu
+// Words (64-bit) of one slot of the slice area: EP_K keys for each of the 64 pixels.  The -DEP_CHECK build appends one
+// checksum per pixel, which the slice wave writes after its list and the merging wave verifies (see the hand-over).
+#ifdef EP_CHECK
+#define EP_SLOT_U64 ((EP_K + 1) * 64)
+// hand-overs verified / hand-overs whose checksum did not match what the merging wave read (diagnostic build only)
+__device__ unsigned long long g_check_seen, g_check_failed;
+// Position-dependent, so a permuted list fails too; seeded with the launch, the tile and the slice, so that a list left
+// in the slot by an earlier launch (or by another tile's slice) fails as well.
+__device__ __forceinline__ unsigned long long check_seed(uint32_t nonce, uint32_t tile, uint32_t slice_no, int lane) {
+    return ((unsigned long long)nonce << 32 | (unsigned long long)tile) * 0x9E3779B97F4A7C15ull ^
+           ((unsigned long long)slice_no << 40 | (unsigned long long)(uint32_t)lane << 8);
+}
+__device__ __forceinline__ unsigned long long check_mix(unsigned long long h, unsigned long long key, int k) {
+    const unsigned long long v = (key + (unsigned long long)(k + 1)) * 0xD6E8FEB86659FD93ull;
+    return h ^ ((v << (k + 1)) | (v >> (63 - k)));
+}
+#else
+#define EP_SLOT_U64 (EP_K * 64)
+#endif
 // The tail of a launch.  When the tiles with real work (EP_TAIL_MIN entries or more) outnumber the wave slots of the GPU
 // and the last round of them would be less than three quarters full, that round would keep most of the GPU idle for the
 // duration of a whole tile.  k_tile_scan then picks a list length, the tail cut, such that the tiles from EP_TAIL_MIN
@@ -859,6 +881,15 @@ __global__ void __launch_bounds__(64) k_splat_bubble(RasterGeom g, egoprior_rast
 // a scalar register needs two other instructions between itself and the VALU instruction that wrote the register, a
 // distance the compiler keeps for its own instructions but not for the operands of inline assembly: here every lane
 // write sits at least three instructions behind its compare by construction.
+//
+// INVARIANT (hardware hazard, not checked by any tool): on gfx950 a VALU read of an SGPR needs >= 2 wait states after
+// the VALU write of that SGPR.  It holds here because
+//   (1) the four compares are ONE asm statement, in the order h0, h1, h2, h3, and nothing can be scheduled into it;
+//   (2) the lane writes are ONE asm statement that consumes the masks in the SAME order (h0 lo, h0 hi, h1 lo, ...), so
+//       the closest pair is compare h0 -> first lane write: compares h1, h2, h3 lie between them (3 >= 2), and every
+//       later pair is farther apart; whatever the compiler places between the two statements only adds distance.
+// Anyone who reorders either list, drops a compare, or splits a statement must re-derive the distances (or put an
+// `s_nop 1` in front of the first lane write); tests/test_gpu_parity.py::test_rasterize_* fail on stale masks.
 __device__ __forceinline__ void hit_masks4(const int L, float d0, float d1, float d2, float d3, float r2, uint32_t& lo,
                                            uint32_t& hi) {
     unsigned long long h0, h1, h2, h3;
@@ -1677,9 +1708,17 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         // the lists are stored write-through instead (agent-scope relaxed atomic stores), the wave waits for its stores
         // to drain and only then counts itself in; the merging wave reads every byte of the other slices' lists with
         // agent-scope loads, which pass its own L1.  No release fence; one acquire, in the merging wave only.
-        u64* const mine_p = sp.partial + (size_t)my_slot * (EP_K * 64) + lane;
+        u64* const mine_p = sp.partial + (size_t)my_slot * EP_SLOT_U64 + lane;
 #pragma unroll
         for (int k = 0; k < EP_K; ++k) __hip_atomic_store(&mine_p[k * 64], kl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef EP_CHECK
+        {
+            u64 h = check_seed(sp.nonce, (uint32_t)tile, slice_no, lane);
+#pragma unroll
+            for (int k = 0; k < EP_K; ++k) h = check_mix(h, kl[k], k);
+            __hip_atomic_store(&mine_p[EP_K * 64], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t before = 0u;
         if (lane == 0) before = __hip_atomic_fetch_add(&sp.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1697,18 +1736,34 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         const uint32_t first = sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
             if (first + o == my_slot) continue;
-            const u64* const theirs = sp.partial + (size_t)(first + o) * (EP_K * 64) + lane;
+            const u64* const theirs = sp.partial + (size_t)(first + o) * EP_SLOT_U64 + lane;
+#ifdef EP_CHECK
+            u64 chk = check_seed(sp.nonce, (uint32_t)tile, o, lane);
+#endif
             // their list is descending like ours: read back to front it is the ascending sequence the merge wants
 #pragma unroll
             for (int p0 = 0; p0 < EP_K; p0 += 10) {
 #pragma unroll
                 for (int p = p0; p < p0 + 10; ++p) {
                     const u64 kb = __hip_atomic_load(&theirs[(EP_K - 1 - p) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef EP_CHECK
+                    chk = check_mix(chk, kb, EP_K - 1 - p);  // the very values that enter the merge
+#endif
                     const u64 ka = kl[p];
                     kl[p] = kb < ka ? kb : ka;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef EP_CHECK
+            {
+                const u64 stored = __hip_atomic_load(&theirs[EP_K * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 bad = __ballot(stored != chk);
+                if (lane == 0) {
+                    atomicAdd(&g_check_seen, 1ull);
+                    if (bad != 0ull) atomicAdd(&g_check_failed, 1ull);
+                }
+            }
+#endif
             merge_network_desc(kl);
         }
     }
@@ -1772,6 +1827,7 @@ k_splat_sweep<512, 512, 3, EP_PIXMAJ, 0>(EP_SPLAT_ARGS) {
 // host side of the C ABI for this file
 // ------------------------------------------------------------------------------------------------------------------
 #include <algorithm>
+#include <atomic>
 
 #include "egoprior_host.h"
 
@@ -1854,7 +1910,7 @@ uint64_t slice_slots_for(uint64_t entries) {
     const uint64_t tail_tiles = std::min<uint64_t>(3 * kWaveSlots / 4, entries / EP_TAIL_MIN);
     return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2 + EP_TAIL_SLICES * tail_tiles;
 }
-constexpr size_t kSlotBytes = (size_t)EP_K * 64 * sizeof(unsigned long long);
+constexpr size_t kSlotBytes = (size_t)EP_SLOT_U64 * sizeof(unsigned long long);
 size_t slice_area_bytes(int n_tiles, uint64_t entries) {
     const uint64_t slots = slice_slots_for(entries);
     return (sizeof(uint32_t) * (2 * (size_t)n_tiles + 64) + 255) / 256 * 256 + (sizeof(uint32_t) * slots + 255) / 256 * 256 +
@@ -1918,7 +1974,7 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
     const size_t rest = bytes - off;
     uint64_t cap = rest / sizeof(ep::ListEntry);
     if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
-    r.slices = ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    r.slices = ep::SlicePlan{};
     if (tn.slices != 0 && tn.splat_variant != 1) {
         // largest capacity whose lists and slice area both fit (the need grows with the capacity: bisection)
         auto need = [&](uint64_t c) { return align_up((size_t)c * sizeof(ep::ListEntry), 256) + slice_area_bytes(n_tiles, c); };
@@ -1943,6 +1999,10 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
             r.slices.partial = (unsigned long long*)q;
             r.slices.max_slots = (uint32_t)(slots > 0x00FFFFFFull ? 0x00FFFFFFull : slots);
             r.slices.wave_slots = tn.tail_slots > 0 ? (uint32_t)tn.tail_slots : 0u;
+#ifdef EP_CHECK
+            static std::atomic<uint32_t> launch_nonce{1u};
+            r.slices.nonce = launch_nonce.fetch_add(1u);
+#endif
         }
     }
     r.capacity = cap;
@@ -2221,11 +2281,24 @@ extern "C" int egoprior_count_list_entries(const egoprior_camera* cam, const ego
     if (int e = launch_count(cam, g, d_a, n_a, d_n_a, d_b, n_b, d_n_b, nullptr, w, tn, s)) return e;
     EP_LAUNCH("k_tile_scan", ep::k_tile_scan<1024>, dim3(1), dim3(1024), 0, s, w.tile_count, w.tile_start, w.tile_cursor,
               w.tile_order, n_tiles, 0xFFFFFFFFu, (int32_t*)nullptr,
-              ep::SlicePlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0u});
+              ep::SlicePlan{});
     EP_LAUNCH("k_copy_total", k_copy_total, dim3(1), dim3(64), 0, s, w.tile_start + n_tiles, d_entries);
     return ep_host::check_launch("count_list_entries");
 }
 
+#ifdef EP_CHECK
+// Diagnostic build only: slice hand-overs whose checksum the merging wave verified, and how many of them did not match.
+extern "C" int egoprior_debug_check_counts(unsigned long long* seen, unsigned long long* failed, int reset) {
+    if (hipMemcpyFromSymbol(seen, HIP_SYMBOL(ep::g_check_seen), sizeof(*seen)) != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(failed, HIP_SYMBOL(ep::g_check_failed), sizeof(*failed)) != hipSuccess) return -3;
+    if (reset) {
+        const unsigned long long z = 0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_check_seen), &z, sizeof(z)) != hipSuccess) return -3;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ep::g_check_failed), &z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
 #ifdef EP_TILE_TIMES
 extern "C" int egoprior_debug_stage_cycles(unsigned long long* host32, int reset) {
     if (hipMemcpyFromSymbol(host32, HIP_SYMBOL(ep::g_stage_cycles), 32 * sizeof(unsigned long long)) != hipSuccess) return -3;

@@ -831,6 +831,23 @@ __global__ void __launch_bounds__(256) k_meanbg_finalize(const float* __restrict
     }
 }
 
+// The viewer's flavour of the finalisation (vipe/utils/viser.py:60-74, 189-192): the means of the pixels of the
+// [::s, ::s] grid only, colours left as float32 means (no quantisation).  A pixel's terms were added in frame order by
+// the accumulate kernels, which is the order torch.nanmean uses whether the stack is subsampled before or after.
+__global__ void __launch_bounds__(256) k_meanbg_finalize_f32(const float* __restrict__ state, int H, int W, int s, int Hs,
+                                                             int Ws, float* __restrict__ mean_depth,
+                                                             float* __restrict__ mean_rgb) {
+    const size_t HW = (size_t)H * W;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)Hs * Ws) return;
+    const size_t j = e / (size_t)Ws, i = e - j * (size_t)Ws;
+    const size_t pix = (j * (size_t)s) * (size_t)W + i * (size_t)s;
+    const float cnt = (float)((const int*)state)[16 * HW + pix];
+    mean_depth[e] = nan_to_num0(folded_sum(state, HW, pix, 0) / cnt);
+#pragma unroll
+    for (int q = 1; q < 4; ++q) mean_rgb[e * 3 + (q - 1)] = nan_to_num0(folded_sum(state, HW, pix, q) / cnt);
+}
+
 __global__ void __launch_bounds__(256) k_meanbg_export(const float* __restrict__ state, int H, int W,
                                                        float* __restrict__ sums4, int32_t* __restrict__ count) {
     const size_t HW = (size_t)H * W;
@@ -1009,12 +1026,27 @@ constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device; written once under g_scratch_mu
 std::mutex g_scratch_mu;
 
-// Address of `scratch` on the current device (resolved on the first call on that device), or NULL with the error text set.
-void* scratch_on_current_device() {
+// Address of `scratch` on the current device (resolved on the first call on that device), or NULL with the error text
+// set.  The kernels run on `stream`: its device must be the current one, or they would be handed another GPU's array.
+void* scratch_on_current_device(hipStream_t stream) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
         ep_host::fail(EGOPRIOR_E_HIP, "hipGetDevice failed (or more than 64 devices)");
         return nullptr;
+    }
+    if (stream != nullptr) {  // (the null stream always belongs to the current device)
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice(stream, &sdev) != hipSuccess) {
+            ep_host::fail(EGOPRIOR_E_HIP, "hipStreamGetDevice failed");
+            return nullptr;
+        }
+        if ((int)sdev != dev) {
+            std::snprintf(ep_host::error_buffer(), 512,
+                          "egoprior_unproject_frame_noalloc: the stream belongs to device %d but device %d is current; "
+                          "make the stream's device current (hipSetDevice) before the call",
+                          (int)sdev, dev);
+            return nullptr;
+        }
     }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (g_scratch_ptr[dev] == nullptr) {
@@ -1044,8 +1076,8 @@ extern "C" int egoprior_unproject_frame_noalloc(const egoprior_unproject_params*
                       (long long)(Hs * Ws), (long long)EGOPRIOR_NOALLOC_MAX_SAMPLES);
         return EGOPRIOR_E_UNSUPPORTED;
     }
-    void* const ptr = scratch_on_current_device();
-    if (ptr == nullptr) return EGOPRIOR_E_HIP;
+    void* const ptr = scratch_on_current_device((hipStream_t)stream);
+    if (ptr == nullptr) return EGOPRIOR_E_INVALID;
     // Nothing in the scratch has to start at zero: the flags kernel writes every flag byte of this frame, the count
     // kernel every block count, the scan (when it runs) every block offset, and nothing beyond this frame's extent is
     // read -- so a call after a larger one is not disturbed by what that one left behind.
@@ -1132,6 +1164,18 @@ extern "C" int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t
     EP_LAUNCH("k_meanbg_finalize", ep::k_meanbg_finalize, dim3((unsigned)((HW + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d_state, H, W, d_mean_depth, d_mean_rgb);
     return ep_host::check_launch("meanbg_finalize");
+}
+
+extern "C" int egoprior_meanbg_finalize_f32(const float* d_state, int32_t H, int32_t W, int32_t subsample,
+                                            float* d_mean_depth, float* d_mean_rgb, void* stream) {
+    if (d_state == nullptr || d_mean_depth == nullptr || d_mean_rgb == nullptr)
+        return ep_host::fail(EGOPRIOR_E_INVALID, "NULL pointer");
+    if (H <= 0 || W <= 0 || subsample <= 0) return ep_host::fail(EGOPRIOR_E_INVALID, "bad sizes");
+    const int Hs = (H + subsample - 1) / subsample, Ws = (W + subsample - 1) / subsample;
+    const size_t n = (size_t)Hs * Ws;
+    EP_LAUNCH("k_meanbg_finalize_f32", ep::k_meanbg_finalize_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+              (hipStream_t)stream, d_state, H, W, subsample, Hs, Ws, d_mean_depth, d_mean_rgb);
+    return ep_host::check_launch("meanbg_finalize_f32");
 }
 
 extern "C" int egoprior_meanbg_export(const float* d_state, int32_t H, int32_t W, float* d_sums4, int32_t* d_count,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "egoprior_meanbg_accumulate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "egoprior_meanbg_accumulate_f16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "egoprior_meanbg_finalize": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "egoprior_meanbg_finalize_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "egoprior_meanbg_export": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "egoprior_meanbg_import": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "egoprior_filter_workspace_bytes": (_sz, [_i64]),

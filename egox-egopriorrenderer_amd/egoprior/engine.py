@@ -268,6 +268,17 @@ class Engine:
             check(self.L.egoprior_meanbg_finalize(_ptr(state), H, W, _ptr(md), _ptr(mc), _stream()))
         return md, mc
 
+    def meanbg_finalize_f32(self, state: torch.Tensor, subsample: int = 1):
+        """The viewer's flavour (vipe/utils/viser.py:189-214): float32 means of the [::s, ::s] pixels, colours unquantised."""
+        _, H, W = state.shape
+        s = int(subsample)
+        Hs, Ws = (H + s - 1) // s, (W + s - 1) // s
+        md = torch.empty((Hs, Ws), dtype=torch.float32, device=self.device)
+        mc = torch.empty((Hs, Ws, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.L.egoprior_meanbg_finalize_f32(_ptr(state), H, W, s, _ptr(md), _ptr(mc), _stream()))
+        return md, mc
+
     def meanbg_export(self, state: torch.Tensor):
         _, H, W = state.shape
         sums = torch.empty((4, H, W), dtype=torch.float32, device=self.device)

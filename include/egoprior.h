@@ -128,7 +128,8 @@ int egoprior_unproject_frame_rays(const egoprior_unproject_params* p, const void
  * EGOPRIOR_E_UNSUPPORTED; every call on a GPU shares that GPU's array, so calls that overlap in time on one GPU
  * (different streams, different threads) race -- serialise them, or use egoprior_unproject_frame with one workspace
  * per stream.  The first call on each device resolves the array's address (hipGetSymbolAddress): make that call outside
- * graph capture. */
+ * graph capture.  The device that owns `stream` must be the current device (each GPU has its own copy of the array, at
+ * its own address); a stream of another device is refused with EGOPRIOR_E_INVALID. */
 #define EGOPRIOR_NOALLOC_MAX_SAMPLES (8 * 1024 * 1024 + 256 * 1024)
 int egoprior_unproject_frame_noalloc(const egoprior_unproject_params* p, const float* d_depth, const uint8_t* d_rgb,
                                      const uint8_t* d_mask, egoprior_point* d_points, double* d_xyz64,
@@ -152,6 +153,12 @@ int egoprior_meanbg_accumulate_f16(float* d_state, const uint16_t* d_depth, cons
                                int32_t F, int64_t first_index, int32_t H, int32_t W, void* stream);
 int egoprior_meanbg_finalize(const float* d_state, int32_t H, int32_t W, float* d_mean_depth, uint8_t* d_mean_rgb,
                              void* stream);
+/* The viewer's mean background, compute_mean_background_depth + compute_robust_mean_tensors of vipe/utils/viser.py:60-74,
+ * 123-214: the frames are masked at full resolution and subsampled [::s, ::s] before they are stacked, and the means stay
+ * float32 (no colour quantisation).  From the same state as egoprior_meanbg_finalize:
+ *   d_mean_depth (ceil(H/s), ceil(W/s)) f32, d_mean_rgb (ceil(H/s), ceil(W/s), 3) f32, NaN (pixels no frame kept) -> 0. */
+int egoprior_meanbg_finalize_f32(const float* d_state, int32_t H, int32_t W, int32_t subsample, float* d_mean_depth,
+                                 float* d_mean_rgb, void* stream);
 int egoprior_meanbg_export(const float* d_state, int32_t H, int32_t W, float* d_sums4, int32_t* d_count, void* stream);
 int egoprior_meanbg_import(float* d_state, int32_t H, int32_t W, const float* d_sums4, const int32_t* d_count,
                            void* stream);

@@ -307,3 +307,172 @@ def test_exact_workspace_sizing_for_large_discs(engine):
     assert np.array_equal(ds.cpu().numpy(), ref_d)
     _, _, _, status = render(L.egoprior_raster_workspace_bytes_entries(S, S, n, need - 300))
     assert status == 1  # the lists no longer fit: reported, nothing written out of bounds
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] at its real size, and the command-line tool's default workload
+# ----------------------------------------------------------------------------------------------------------------------
+def _fisheye_cam(frame_no, n_frames, S):
+    from egoprior import synth
+    from egoprior import engine as eng
+    from egoprior.render_vipe_pointcloud import load_aria_distortion_coeffs
+    radial, tangential, thin_prism, _, _ = load_aria_distortion_coeffs(None)
+    exo = synth.exo_w2c()
+    R, t = eng.split_w2c(synth.ego_orbit_w2c(n_frames, exo)[frame_no])
+    # the ego intrinsics of the Ego-Exo4D camera-pose files (aria01: f = 150, c = 255.5 on 512 px), recentred for S px
+    return eng.fisheye_camera(R, t, 150.0, S / 2.0, S / 2.0, radial, tangential, thin_prism, S, S)
+
+
+def _brute_force_pixels(ndc, res, rp, S, pix):
+    """Plain torch float32 search over ALL points for the given pixels: the K smallest (z, index) among the discs that
+    cover the pixel centre, compared with the kernel's index map."""
+    dev = ndc.device
+    x, y, z = ndc[:, 0].contiguous(), ndc[:, 1].contiguous(), ndc[:, 2].contiguous()
+    zbits = torch.where(z == 0, torch.zeros_like(z), z).view(torch.int32).long()
+    key_all = (zbits << 32) | torch.arange(ndc.shape[0], device=dev)
+    live = z >= 0
+    xf, yf = O.pixel_ndc_centres(S, S)
+    xf, yf = torch.from_numpy(xf).to(dev), torch.from_numpy(yf).to(dev)
+    r2 = float(np.float32(rp.radius) * np.float32(rp.radius))
+    big = torch.iinfo(torch.int64).max
+    for c0 in range(0, len(pix), 16):
+        chunk = pix[c0:c0 + 16]
+        py = torch.tensor([p[0] for p in chunk], device=dev)
+        px = torch.tensor([p[1] for p in chunk], device=dev)
+        dx = x[None, :] - xf[px][:, None]
+        dy = y[None, :] - yf[py][:, None]
+        dx2 = dx * dx
+        dy2 = dy * dy
+        d2 = dx2 + dy2
+        hit = (d2 < r2) & live[None, :]
+        keys = torch.where(hit, key_all[None, :], torch.full_like(key_all[None, :], big))
+        best = torch.topk(keys, K, dim=1, largest=False, sorted=True).values
+        want = torch.where(best == big, torch.full_like(best, -1), best & 0xFFFFFFFF).int()
+        assert torch.equal(res["idx"][py, px], want), f"pixels {chunk}"
+
+
+def test_fisheye_448_point_size_20_at_full_size(engine, scene):
+    """BASELINE configs[3] as the reference runs it (scripts/render_vipe.sh: fisheye, 448 x 448) with the static and the
+    dynamic points of a 1080p exo frame and point_size 20: discs of 20 px radius, tens of tiles per disc, and -- the
+    fisheye periphery packs far more points into some tiles than others -- tile lists long enough to be cut into slices.
+    Variants agree, slicing on and off agrees, sampled pixels match a brute-force search over all points."""
+    from egoprior import _lib
+    from egoprior import engine as eng
+    S, ps = 448, 20.0
+    cam = _fisheye_cam(40, 300, S)
+    rp = eng.make_raster_params(ps, S, S, K=K, rotate_cw=False, colors_gt1=-1)
+
+    def render(variant, slices):
+        _lib.set_option("splat_variant", variant)
+        _lib.set_option("slices", slices)
+        try:
+            r = engine.render_frame(cam, rp, scene["bg"], scene["dyn"], want_f32=True, want_fragments=True)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("splat_variant", 0)
+            _lib.set_option("slices", 1)
+        assert r["status"].item() == 0
+        return r
+
+    ref = render(0, 1)
+    covered = (ref["idx"][..., 0] >= 0).float().mean().item()
+    assert covered > 0.5, covered
+    assert (ref["idx"][..., K - 1] >= 0).float().mean().item() > 0.4  # most pixels hold all K fragments
+    for variant, slices in ((0, 0), (3, 1), (1, 1)):
+        got = render(variant, slices)
+        for key in ("idx", "zbuf", "dists", "image_f32", "image"):
+            assert torch.equal(got[key], ref[key]), f"variant {variant}, slices {slices}: {key} differs"
+    n = scene["n"]
+    ndc = engine.project_points(cam, scene["bg"], scene["dyn"])[:n]
+    rng = np.random.default_rng(21)
+    pix = [(int(a), int(b)) for a, b in zip(rng.integers(0, S, 96), rng.integers(0, S, 96))]
+    pix += [(yy, xx) for yy in (0, 7, 8, 223, 224, S - 1) for xx in (0, 7, 8, 223, 224, S - 1)]
+    _brute_force_pixels(ndc, ref, rp, S, pix)
+    engine._ws.pop("render", None)
+
+
+def _check_build(engine):
+    """An Engine that calls the -DEP_CHECK build of the library (every slice hand-over of the splat kernel carries a
+    checksum which the merging wave verifies), or None when that build is not there."""
+    import copy
+    import ctypes as C
+    from egoprior import _lib
+    path = _lib.CSRC / "libegoprior_hip_check.so"
+    if not path.exists():
+        return None, None
+    L = C.CDLL(str(path))
+    for name, (rt, args) in _lib.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = rt, args
+    L.egoprior_debug_check_counts.restype = C.c_int
+    L.egoprior_debug_check_counts.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
+    E2 = copy.copy(engine)
+    E2.L = L
+    E2._ws = {}
+    return E2, L
+
+
+def test_accumulated_cloud_of_the_cli_default_mode(engine):
+    """What `python scripts/render_vipe_pointcloud.py` renders without --use_mean_bg: the static points of every frame of
+    a clip accumulated into one cloud (scripts/render_vipe_pointcloud.py:304-456) -- 64 frames of 1080p at subsample 2,
+    more than 30 M points, 64 near-copies of every surface point -- on the 448 x 448 fisheye image at point_size 5.  A few
+    hundred tiles hold hundreds of thousands of entries each and are cut into up to 64 slices.  Index maps, z-buffers and
+    distances against the oracle's scatter rasterizer, with slicing on and off; then the same frame through the -DEP_CHECK
+    build, in which every slice stores a checksum behind its per-pixel lists and the merging wave verifies that what it
+    read is what was written."""
+    import ctypes as C
+    from egoprior import _lib, synth
+    from egoprior import engine as eng
+    dev = engine.device
+    F, Hx, Wx, S, ps = 64, 1080, 1920, 448, 5.0
+    exo = synth.exo_w2c()
+    T = np.linalg.inv(exo)
+    intr, c2w = synth.exo_intrinsics(Hx, Wx), np.eye(4, dtype=np.float32)
+    ns = (Hx // 2) * (Wx // 2)
+    big = torch.empty((F * ns, 4), dtype=torch.float32, device=dev)
+    tmp = engine.new_cloud(ns)
+    total = 0
+    for f0 in range(0, F, 16):
+        d, rgb, m = synth.make_frames(Hx, Wx, list(range(f0, f0 + 16)), F, device=dev)
+        for j in range(16):
+            engine.unproject_frame(d[j], rgb[j], m[j], intr, c2w, T, subsample=2, select=_lib.SELECT_STATIC, out=tmp)
+            n = tmp.n()
+            big[total:total + n] = tmp.points[:n]
+            total += n
+        del d, rgb, m
+    assert total > 30_000_000
+    cloud = eng.DeviceCloud(points=big[:total], count=torch.tensor([total], dtype=torch.int32, device=dev),
+                            flags=torch.ones(1, dtype=torch.int32, device=dev))
+    cam = _fisheye_cam(10, F, S)
+    ndc = engine.project_points(cam, cloud)[:total].contiguous()
+    del big, cloud
+    rp = eng.make_raster_params(ps, S, S, K=K, colors_gt1=1)
+    ref_idx, ref_z, ref_d = O.rasterize(ndc[:, :3].cpu().numpy(), O.radius_ndc(ps, S, S), S, S, K, "scatter")
+    assert (ref_idx[..., K - 1] >= 0).mean() > 0.3
+
+    def check(E, slices):
+        E.L.egoprior_set_option(b"slices", slices)
+        try:
+            res = E.rasterize_composite(ndc, None, rp, S, S, want_fragments=True)
+            torch.cuda.synchronize()
+        finally:
+            E.L.egoprior_set_option(b"slices", 1)
+        assert res["status"].item() == 0
+        assert np.array_equal(res["idx"].cpu().numpy(), ref_idx), f"slices {slices}: idx"
+        assert np.array_equal(res["zbuf"].cpu().numpy(), ref_z), f"slices {slices}: zbuf"
+        assert np.array_equal(res["dists"].cpu().numpy(), ref_d), f"slices {slices}: dists"
+
+    check(engine, 1)
+    check(engine, 0)
+    engine._ws.pop("raster", None)
+    E2, L2 = _check_build(engine)
+    if E2 is None:
+        pytest.skip("libegoprior_hip_check.so is not built (make -C egox-egopriorrenderer_amd/csrc libegoprior_hip_check.so)")
+    seen, failed = C.c_ulonglong(0), C.c_ulonglong(0)
+    assert L2.egoprior_debug_check_counts(C.byref(seen), C.byref(failed), 1) == 0
+    for _ in range(3):  # the slot memory is reused from launch to launch: stale lists of the launch before must not pass
+        check(E2, 1)
+    assert L2.egoprior_debug_check_counts(C.byref(seen), C.byref(failed), 1) == 0
+    print(f"slice hand-overs verified: {seen.value}, checksum mismatches: {failed.value}")
+    assert seen.value > 3 * 1000, seen.value   # a few hundred sliced tiles with dozens of slices each, three launches
+    assert failed.value == 0

@@ -14,7 +14,7 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _both(engine, H, W, s, select, frame_id):
+def _both(engine, H, W, s, select, frame_id, warmed=True):
     from egoprior import _lib, synth
     from egoprior import engine as eng
     L, dev = engine.L, engine.device
@@ -36,8 +36,15 @@ def _both(engine, H, W, s, select, frame_id):
             _lib.check(L.egoprior_unproject_frame(C.byref(p), _p(d), _p(rgb), _p(m), _p(pts), _p(x64), _p(cnt), _p(flg),
                                                   _p(ws), ws.numel(), stream))
         else:
+            # nothing may be allocated by the call: neither through torch's allocator nor behind its back (hipMemGetInfo)
+            torch.cuda.synchronize()
+            before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev), torch.cuda.mem_get_info(dev)[0])
             _lib.check(L.egoprior_unproject_frame_noalloc(C.byref(p), _p(d), _p(rgb), _p(m), _p(pts), _p(x64), _p(cnt),
                                                           _p(flg), stream))
+            torch.cuda.synchronize()
+            after = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev), torch.cuda.mem_get_info(dev)[0])
+            if warmed:  # (the very first call on a device may load the code object that holds the scratch array)
+                assert after == before, f"device memory changed across the call: {before} -> {after}"
         torch.cuda.synchronize()
         res.append((pts, x64, cnt, flg))
     return res
@@ -48,7 +55,7 @@ def test_noalloc_unprojection_matches_the_workspace_entry_point(engine):
     # first call: a 1080p frame at subsample 1 (2 025 compaction blocks); second: a smaller frame, other rule and stride
     for (H, W, s, select, fid) in ((1080, 1920, 1, _lib.SELECT_STATIC, 2), (270, 484, 2, _lib.SELECT_DYNAMIC, 5),
                                    (120, 208, 1, _lib.SELECT_STATIC, 1)):
-        (pa, xa, ca, fa), (pb, xb, cb, fb) = _both(engine, H, W, s, select, fid)
+        (pa, xa, ca, fa), (pb, xb, cb, fb) = _both(engine, H, W, s, select, fid, warmed=(H != 1080))
         n = int(ca.item())
         assert n == int(cb.item()) and n > 0
         assert int(fa.item()) == int(fb.item())

@@ -319,8 +319,8 @@ def _fisheye_cam(frame_no, n_frames, S):
     radial, tangential, thin_prism, _, _ = load_aria_distortion_coeffs(None)
     exo = synth.exo_w2c()
     R, t = eng.split_w2c(synth.ego_orbit_w2c(n_frames, exo)[frame_no])
-    # the ego intrinsics of the Ego-Exo4D camera-pose files (aria01: f = 150, c = 255.5 on 512 px), recentred for S px
-    return eng.fisheye_camera(R, t, 150.0, S / 2.0, S / 2.0, radial, tangential, thin_prism, S, S)
+    K = synth.ego_pinhole_K(S, S)  # the ego intrinsics bench.py --fisheye passes: f = 0.6 S, centred
+    return eng.fisheye_camera(R, t, K[0, 0], K[0, 2], K[1, 2], radial, tangential, thin_prism, S, S)
 
 
 def _brute_force_pixels(ndc, res, rp, S, pix):
@@ -376,8 +376,8 @@ def test_fisheye_448_point_size_20_at_full_size(engine, scene):
 
     ref = render(0, 1)
     covered = (ref["idx"][..., 0] >= 0).float().mean().item()
-    assert covered > 0.5, covered
-    assert (ref["idx"][..., K - 1] >= 0).float().mean().item() > 0.4  # most pixels hold all K fragments
+    assert covered > 0.25, covered
+    assert (ref["idx"][..., K - 1] >= 0).float().mean().item() > 0.8 * covered  # covered pixels hold all K fragments
     for variant, slices in ((0, 0), (3, 1), (1, 1)):
         got = render(variant, slices)
         for key in ("idx", "zbuf", "dists", "image_f32", "image"):

@@ -398,38 +398,54 @@ def run(args):
                 pmc = json.load(open(tr))
             except Exception:
                 pmc = {}
-        if pmc.get(dominant):
-            roofline["traffic"] = pmc[dominant]
+        rec = pmc.get("kernels", {}).get(dominant)
+        if rec:
+            # Counters come from the committed rocprofv3 passes (profiles/), collected on `pmc["_command"]`; the launch
+            # duration is measured here.  `frames_match` says whether this run renders the frames the counters cover (the
+            # splat's cost follows the ego orbit, so figures from different frames do not combine exactly).
+            same = (args.steps == pmc.get("_steps") and args.warmup == pmc.get("_warmup") and args.frames == 300
+                    and args.point_size == 5.0 and not args.fisheye and args.subsample == 1)
+            roofline["traffic"] = rec["bytes_corrected"]
+            roofline["traffic_uncorrected"] = rec["bytes_uncorrected"]
             if k["algorithmic_bytes"]:
-                roofline["traffic_ratio"] = round(pmc[dominant] / k["algorithmic_bytes"], 2)
-        sq = pmc.get("_sq_per_launch", {}).get(dominant, {})
-        insts = sq.get("SQ_INSTS_VALU")
-        if insts and dominant in ("k_splat_sweep", "k_splat_bubble"):
-            # ... but what bounds the splat kernel is vector-instruction issue (exact top-20 per pixel: hit tests, sort,
-            # merge), so the fraction is taken against that peak: one wave64 VALU instruction per 2 cycles and SIMD (the
-            # rate MI355X_MICROARCH.md gives for a SIMD shared by two or more waves), 1024 SIMDs, 2.4 GHz.  The HBM figures
-            # stay alongside.  `valu_busy_measured` is the VALU pipes' own busy counter over the kernel's duration:
-            # the instruction mix here (64-bit compares, DPP operands, packed float math, three-operand forms) issues
-            # at 3 to 4 cycles per instruction, not 2 (tools/ubench/valu_issue.hip measures the forms one by one).
-            simds, clock = 1024, 2.4e9
-            peak = simds * clock / 2 / 1e9
-            ach = insts / (k["avg_us"] * 1e-6) / 1e9
-            roofline = {"kernel": dominant, "bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
-                        "unit": "G wave-instructions/s", "frac": round(ach / peak, 3),
-                        "traffic": roofline["traffic"], "traffic_ratio": roofline["traffic_ratio"],
-                        "avg_us": k["avg_us"], "valu_wave_insts_per_launch": insts,
-                        "valu_cycles_per_inst_assumed": 2,
-                        "hbm": {"achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac_hbm"],
-                                "algorithmic_bytes": k["algorithmic_bytes"]},
-                        "source": "profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE and SQ passes of the same "
-                                  "command), avg_us measured here with HIP events"}
-            busy = sq.get("SQ_ACTIVE_INST_VALU")
-            if busy:  # quad-cycles in which a SIMD's vector ALU was executing, summed over the SIMDs
-                roofline["valu_busy_measured"] = round(busy * 4 / (simds * clock * k["avg_us"] * 1e-6), 3)
-            roofline["note"] = ("algorithmic bytes = 16 B per projected point + 3 B per output pixel; the measured traffic "
-                                "is a multiple of that: tile lists (8 B per point-tile pair), the gathers of NDC x, y for "
-                                "the entries that pass the threshold filter and the compositor's gathers of the winners' "
-                                "records")
+                roofline["traffic_ratio"] = round(rec["bytes_corrected"] / k["algorithmic_bytes"], 2)
+                roofline["traffic_ratio_uncorrected"] = round(rec["bytes_uncorrected"] / k["algorithmic_bytes"], 2)
+            roofline["source"] = (f"profiles/pmc_traffic.json ({pmc.get('_round')}: {pmc.get('_command')}; "
+                                  f"{pmc.get('_frames')}); avg_us measured here with HIP events on this run's frames "
+                                  f"{args.warmup}..{args.warmup + args.steps - 1}")
+            roofline["frames_match"] = bool(same)
+            sq, ldsc = rec.get("sq", {}), rec.get("lds", {})
+            insts = sq.get("SQ_INSTS_VALU")
+            if insts and dominant in ("k_splat_sweep", "k_splat_bubble"):
+                # What bounds the splat kernel is vector-instruction issue (exact top-20 per pixel: hit tests, sort, merge),
+                # so the fraction is taken against that peak: one wave64 VALU instruction per 2 cycles and SIMD (the rate
+                # MI355X_MICROARCH.md gives for a SIMD shared by two or more waves), 1024 SIMDs, 2.4 GHz.  The HBM figures
+                # stay alongside.  `valu_busy_measured` is the VALU pipes' own busy counter over the kernel's duration: the
+                # instruction mix here (64-bit compares, DPP operands, packed float math, three-operand forms) issues at 3
+                # to 4 cycles per instruction, not 2 (tools/ubench/valu_issue.hip measures the forms one by one).
+                simds, clock = 1024, 2.4e9
+                peak = simds * clock / 2 / 1e9
+                ach = insts / (k["avg_us"] * 1e-6) / 1e9
+                hbm = {"achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac_hbm"],
+                       "algorithmic_bytes": k["algorithmic_bytes"]}
+                roofline.update({"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1),
+                                 "unit": "G wave-instructions/s", "frac": round(ach / peak, 3),
+                                 "valu_wave_insts_per_launch": insts, "valu_cycles_per_inst_assumed": 2, "hbm": hbm})
+                busy = sq.get("SQ_ACTIVE_INST_VALU")
+                if busy:  # quad-cycles in which a SIMD's vector ALU was executing, summed over the SIMDs
+                    roofline["valu_busy_measured"] = round(busy * 4 / (simds * clock * k["avg_us"] * 1e-6), 3)
+                roofline["note"] = ("algorithmic bytes = 16 B per projected point + 3 B per output pixel; the measured "
+                                    "traffic is a multiple of that: tile lists (8 B per point-tile pair), the gathers of NDC "
+                                    "x, y for the entries that pass the threshold filter and the compositor's gathers of the "
+                                    "winners' records")
+            wc, ga = sq.get("SQ_WAVE_CYCLES"), sq.get("GRBM_GUI_ACTIVE")
+            if wc and ga:
+                # wave-cycles (units of 4 clocks) over the kernel's busy clocks = waves resident on average; the kernel
+                # runs 3 waves per SIMD, 3072 on the chip
+                roofline["resident_waves_avg"] = round(4.0 * wc / ga, 1)
+                roofline["occupancy"] = round(4.0 * wc / ga / 3072.0, 3)
+            if ldsc.get("SQ_LDS_IDX_ACTIVE"):
+                roofline["lds_conflict_frac"] = round(ldsc.get("SQ_LDS_BANK_CONFLICT", 0) / ldsc["SQ_LDS_IDX_ACTIVE"], 3)
 
     cpu = None
     if not args.skip_cpu and world == 1:

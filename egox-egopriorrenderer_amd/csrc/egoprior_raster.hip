@@ -958,8 +958,9 @@ constexpr int next_pow2(int v) {
 // positions (all ones) come first.  With the chunk's winners B in ascending order, min(list[p], B[p]) for every p is
 // then the EP_K smallest keys of both as a rising-then-falling sequence, which the network sorts back to descending
 // order without any scratch registers.
-// LDS per wave = C*16 (sorted records) + max(NB*4, C*8) (bucket table, hit masks and threshold tables share the space):
-// 10.5 KiB for C = 448 (the default), 12 KiB for C = 512; three waves per SIMD (12 per CU) in the 160 KiB of a CU.
+// LDS per wave = C*16 (sorted records) + max(NB*4, C*8) (bucket table and hit masks share the space) + 1.1 KiB of
+// threshold tables: 11.6 KiB for C = 448 (the default), 13.1 KiB for C = 512; three waves per SIMD (12 per CU) in the
+// 160 KiB of a CU.
 // Sorts a list that rises and then falls (the element-wise minimum of a descending list and an ascending one) back into
 // descending order: a bitonic merge for a length that is not a power of two (EP_K = 16 + 4); positions 20 .. 31 would
 // hold minus infinity and never move, so the exchanges with them are left out.
@@ -995,12 +996,10 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     constexpr int RPL = C / 64;   // records per lane while a chunk is being organised
     constexpr int PER = NB / 64;  // buckets per lane
     __shared__ uint4 S[C];        // x = point index, y = z bits, z = NDC x bits, w = NDC y bits; sorted by (y, x)
-    // The bucket counters are dead once a chunk is sorted, the hit masks (one 64-bit word per pixel and block of 64
-    // records) are dead once it is merged and the threshold tables are only read while the next chunk is gathered, so the
-    // three share storage.
+    // The bucket counters are dead once a chunk is sorted and the hit masks (one 64-bit word per pixel and block of 64
+    // records) are only alive from the sweep to the merge, so the two share storage.
     constexpr int AUX0 = (NB * 4 > C * 8) ? NB * 4 : C * 8;
-    constexpr int AUXB = AUX0 > 2 * 64 * 8 + 16 * 8 ? AUX0 : 2 * 64 * 8 + 16 * 8;
-    __shared__ __align__(16) unsigned char aux[AUXB];
+    __shared__ __align__(16) unsigned char aux[AUX0];
     uint32_t* const bkt = reinterpret_cast<uint32_t*>(aux);
     uint32_t(*const masks)[64] = reinterpret_cast<uint32_t(*)[64]>(aux);  // row 2 b + h: records 32 h .. 32 h + 31 of block b
 
@@ -1079,9 +1078,13 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     // rows a..b of the tile (all ones while a pixel's list is not full), colband the same for columns.  A record can
     // only enter the list of a pixel its disc reaches, and min(rowband[rows it reaches], colband[columns it reaches]) is
     // an upper bound on the K-th keys of those pixels.
-    u64* const rowband = reinterpret_cast<u64*>(aux);
+    // The tables have LDS of their own (1.1 KiB), so that they outlive the chunk after the one they were built for: a
+    // pixel's K-th key only ever falls, which keeps an old table a valid bound, and the tables of a long list change
+    // little from chunk to chunk.  They are rebuilt after chunks 2, 3, 4, 6, 8, 12, 16, 24, 32, ... (building them is two
+    // wave-wide reductions, two barriers and a short divergent loop: as much as gathering a batch of keys).
+    __shared__ u64 band_tables[2 * 64 + 16];
+    u64* const rowband = band_tables;
     u64* const colband = rowband + 64;
-    static_assert(AUXB >= 2 * 64 * 8 + 16 * 8, "threshold tables fit");
     const float inv_pitch = uniform_f32(0.5f * (float)min(g.W, g.H));           // pixels per NDC unit
     const float reach_px = uniform_f32(sqrtf(r2) * inv_pitch + 0.01f);          // the margin covers every rounding
 
@@ -1502,6 +1505,8 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         for (int d = 32; d >= 1; d >>= 1) m_sweep = max(m_sweep, __shfl_xor(m_sweep, d));
         m_sweep = (int)uniform_u32((uint32_t)m_sweep);
         int n_blocks = 0;  // blocks of 64 records that the sweep has offered to the pixels
+        static_assert(2 * (C / 64) <= 32, "one bit per mask word");
+        uint32_t nz_words = 0u;  // bit w: mask word w of this lane (32 records each) is not empty
         // the tile's eight pixel columns and rows as wave-uniform values (lanes 0..7 hold the columns, every eighth lane a row)
         float xcol[8], yrow[8];
 #pragma unroll
@@ -1600,6 +1605,9 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             // most hits, was a third of the kernel's instructions).
             masks[2 * n_blocks][lane] = hm_lo;
             masks[2 * n_blocks + 1][lane] = hm_hi;
+            // which of the lane's mask words hold a hit at all: the walk below goes from one such word to the next
+            nz_words |= ((hm_lo != 0u) ? 1u : 0u) << (2 * n_blocks);
+            nz_words |= ((hm_hi != 0u) ? 2u : 0u) << (2 * n_blocks);
             cnt = min(cnt + (int)(__popc(hm_lo) + __popc(hm_hi)), K);
             ++n_blocks;
         }
@@ -1623,13 +1631,19 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         // positions in S of the lane's winners, in ascending key order: the first `won` set bits of its masks
         uint32_t widx[EP_K];
         {
+            // Words without a hit are never read: with a few winners spread over a long chunk (the later chunks of a
+            // heavy tile) the walk used to spend its time on dependent LDS reads of empty words.
             int row = 0;  // 32 records per mask word
-            uint32_t word = (n_blocks > 0) ? masks[0][lane] : 0u;
+            uint32_t word = 0u, todo = nz_words;
 #pragma unroll
             for (int p = 0; p < EP_K; ++p) {
                 widx[p] = 0u;
                 if (p < won) {
-                    while (word == 0u) word = masks[++row][lane];  // ends: the lane has more than p hits in all
+                    if (word == 0u) {  // next word that holds a hit (there is one: the lane has more than p hits in all)
+                        row = __builtin_ctz(todo);
+                        todo &= todo - 1u;
+                        word = masks[row][lane];
+                    }
                     widx[p] = (uint32_t)(row * 32 + __builtin_ctz(word));
                     word &= word - 1u;
                 }
@@ -1663,8 +1677,10 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             T = wave_max_u64(mine);
         }
         EP_MSTAGE(2)
-        if (pos < end && chunk_no > 1) {
-            // threshold tables for the next gather: row / column maxima of the K-th keys, then every band of them
+        const int c3 = chunk_no / 3;
+        const bool bands_due = chunk_no <= 4 || (chunk_no & (chunk_no - 1)) == 0 || (c3 * 3 == chunk_no && (c3 & (c3 - 1)) == 0);
+        if (pos < end && chunk_no > 1 && bands_due) {
+            // threshold tables for the next gathers: row / column maxima of the K-th keys, then every band of them
             const u64 mine = inside ? kth_key() : 0ull;
             u64 rmax = mine, cmax = mine;
 #pragma unroll
@@ -1678,7 +1694,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
                 cmax = o > cmax ? o : cmax;
             }
             u64* const line = colband + 64;  // 8 row maxima, 8 column maxima
-            __syncthreads();                 // the merge's reads of the hit masks are done
+            __syncthreads();                 // (the tables' last readers, the previous gather, are long done)
             if ((lane & 7) == 0) line[lane >> 3] = rmax;
             if (lane < 8) line[8 + lane] = cmax;
             __syncthreads();
@@ -1801,8 +1817,8 @@ __global__ void __launch_bounds__(64, WPE) k_splat_sweep(EP_SPLAT_ARGS) {
                                                out);
 }
 // The default geometry, 448-entry chunks, is compiled for 144 registers (the attribute counts in units of two on this
-// target) instead of the 168 that three waves per SIMD would allow, and takes 10.5 KiB of LDS per wave.  Twelve splat waves
-// then leave a compute unit 80 registers per SIMD and 34 KiB of LDS: room for a workgroup of any other kernel of the
+// target) instead of the 168 that three waves per SIMD would allow, and takes 11.6 KiB of LDS per wave.  Twelve splat waves
+// then leave a compute unit 80 registers per SIMD and 20 KiB of LDS: room for a workgroup of any other kernel of the
 // frames in flight (40 to 64 registers per wave, up to 12.5 KiB of LDS), which otherwise waits for splat waves to retire.
 // Nothing spills at seven records per lane.
 template <>
@@ -2131,7 +2147,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
             EP_PROBE_CASE(14, 4)
 #undef EP_PROBE_CASE
 #endif
-        default:  // 448-record chunks, 10.5 KiB of LDS per wave, three waves per SIMD
+        default:  // 448-record chunks, 11.6 KiB of LDS per wave, three waves per SIMD
             EP_SWEEP(448, 512, 3);
     }
 #undef EP_SWEEP

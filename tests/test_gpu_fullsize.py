@@ -448,7 +448,7 @@ def test_accumulated_cloud_of_the_cli_default_mode(engine):
     del big, cloud
     rp = eng.make_raster_params(ps, S, S, K=K, colors_gt1=1)
     ref_idx, ref_z, ref_d = O.rasterize(ndc[:, :3].cpu().numpy(), O.radius_ndc(ps, S, S), S, S, K, "scatter")
-    assert (ref_idx[..., K - 1] >= 0).mean() > 0.3
+    assert (ref_idx[..., K - 1] >= 0).mean() > 0.2
 
     def check(E, slices):
         E.L.egoprior_set_option(b"slices", slices)

@@ -1,19 +1,30 @@
 """Turns the raw output of tools/profile_round.sh (gpurun_out/prof_<round>/) into the committed summaries under profiles/:
-<round>_kernel_stats.csv (all kernels), <round>_kernel_stats_ep.csv (this library's kernels), pmc_traffic.json (HBM
-bytes per launch, gfx950 read-side correction applied) and <round>_pmc_sq.txt (SQ instruction counters per launch).
-usage: python tools/make_profiles.py r01"""
+  <round>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of the profiled command, every kernel of the process
+  <round>_kernel_stats_ep.csv   ... this library's kernels only
+  <round>_pmc_sq.txt            SQ / GRBM counters, per-launch means
+  <round>_pmc_lds.txt           LDS counters, per-launch means
+  <round>_pmc_hbm.txt           FETCH_SIZE / WRITE_SIZE (KiB), per-launch means
+  pmc_traffic.json              all of the above per kernel, the command they were collected on and the frames it renders;
+                                bench.py reads the dominant kernel's entry for its `roofline` object
+Per-launch means leave out each kernel's first `warmup` launches (the command's untimed warm-up frames), so that the
+counters cover exactly the frames the timing covers.
+usage: python tools/make_profiles.py r03"""
 import csv
 import json
+import re
 import shutil
 import sys
 from collections import defaultdict
 from pathlib import Path
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = Path(__file__).resolve().parents[1]
 src = ROOT / "gpurun_out" / f"prof_{R}"
 dst = ROOT / "profiles"
 dst.mkdir(exist_ok=True)
+command = (src / "command.txt").read_text().strip() if (src / "command.txt").exists() else "bench.py"
+m_steps, m_warm = re.search(r"--steps (\d+)", command), re.search(r"--warmup (\d+)", command)
+steps, warmup = int(m_steps.group(1)) if m_steps else 200, int(m_warm.group(1)) if m_warm else 20
 
 
 def short(name):
@@ -38,36 +49,57 @@ with open(dst / f"{R}_kernel_stats_ep.csv", "w", newline="") as fh:
 
 
 def counters(sub):
-    acc = defaultdict(lambda: defaultdict(list))
-    for f in [newest((src / sub).rglob("*counter_collection.csv"))]:
-        with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
-                if "ep::" in row["Kernel_Name"]:
-                    acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+    """{kernel: {counter: mean over the launches after the warm-up}}, and the number of launches averaged."""
+    per = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> [(dispatch id, value)]
+    f = newest((src / sub).rglob("*counter_collection.csv"))
+    with open(f, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if "ep::" in row["Kernel_Name"]:
+                per[short(row["Kernel_Name"])][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+    out, n = {}, {}
+    for k, d in per.items():
+        out[k] = {}
+        for c, v in d.items():
+            v = [x for _, x in sorted(v)]
+            v = v[warmup:] if len(v) > warmup else v
+            out[k][c] = sum(v) / len(v)
+            n[k] = len(v)
+    return out, n
 
 
-fetch, write = counters("pmc_fetch"), counters("pmc_write")
-out = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units), bench.py "
-                "workload (1080p exo, 480x832 ego, point_size 5), one frame in flight. gfx950 correction applied: "
-                "FETCH_SIZE counts 128-B read requests as 64 B, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is "
-                "exact for 16-B-per-lane stores.",
-       "_round": R}
-for k in sorted(set(fetch) | set(write)):
+fetch, n_f = counters("pmc_fetch")
+write, _ = counters("pmc_write")
+sq, n_sq = counters("pmc_sq") if (src / "pmc_sq").exists() else ({}, {})
+lds, _ = counters("pmc_lds") if (src / "pmc_lds").exists() else ({}, {})
+out = {"_note": "Per-launch means of rocprofv3 --pmc passes (one pass per counter group, no trace alongside) over the launches "
+                "of the timed frames.  HBM bytes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte "
+                "read request as 64 bytes, so streaming reads (16 bytes per lane) are 2 x FETCH_SIZE; for scattered 8- and "
+                "16-byte gathers the factor lies between 1 and 2, hence both figures are kept: bytes_corrected = "
+                "(2 FETCH + WRITE) * 1024, bytes_uncorrected = (FETCH + WRITE) * 1024.  SQ cycle counters are in units of "
+                "4 clocks.",
+       "_round": R, "_command": "python3 " + command, "_steps": steps, "_warmup": warmup,
+       "_frames": f"exo / ego frames {warmup}..{warmup + steps - 1} of the synthetic clip's orbit (the first {warmup} launches of "
+                  "every kernel, the warm-up frames, are left out of the means)",
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write) | set(sq)):
     f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
     w_ = write.get(k, {}).get("WRITE_SIZE", 0.0)
-    out[k] = int(2 * f * 1024 + w_ * 1024)
-    out[k + "__raw_KiB"] = {"FETCH_SIZE": round(f, 1), "WRITE_SIZE": round(w_, 1)}
-sq = counters("pmc_sq") if (src / "pmc_sq").exists() else {}
-if sq:
-    out["_sq_per_launch"] = {k: {c: int(v) for c, v in d.items()} for k, d in sorted(sq.items())}
-    with open(dst / f"{R}_pmc_sq.txt", "w") as fh:
-        for k, d in sorted(sq.items()):
-            fh.write(f"{k:28s} " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(d.items())) + "\n")
-lds = counters("pmc_lds") if (src / "pmc_lds").exists() else {}
-if lds:
-    with open(dst / f"{R}_pmc_lds.txt", "w") as fh:
-        for k, d in sorted(lds.items()):
-            fh.write(f"{k:28s} " + "  ".join(f"{c}={v:.4g}" for c, v in sorted(d.items())) + "\n")
+    out["kernels"][k] = {"launches_averaged": n_f.get(k, n_sq.get(k, 0)),
+                         "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w_, 1),
+                         "bytes_corrected": int((2 * f + w_) * 1024), "bytes_uncorrected": int((f + w_) * 1024),
+                         "sq": {c: int(v) for c, v in sorted(sq.get(k, {}).items())},
+                         "lds": {c: int(v) for c, v in sorted(lds.get(k, {}).items())}}
+with open(dst / f"{R}_pmc_hbm.txt", "w") as fh:
+    fh.write(f"# {out['_command']}; {out['_frames']}\n")
+    for k, d in out["kernels"].items():
+        fh.write(f"{k:28s} FETCH_SIZE={d['FETCH_SIZE_KiB']} KiB  WRITE_SIZE={d['WRITE_SIZE_KiB']} KiB  launches={d['launches_averaged']}\n")
+for name, table in (("sq", sq), ("lds", lds)):
+    if table:
+        with open(dst / f"{R}_pmc_{name}.txt", "w") as fh:
+            fh.write(f"# {out['_command']}; {out['_frames']}\n")
+            for k, d in sorted(table.items()):
+                fh.write(f"{k:28s} " + "  ".join(f"{c}={v:.6g}" for c, v in sorted(d.items())) + "\n")
+if (src / "bench_plain.json").exists():
+    shutil.copy(src / "bench_plain.json", dst / f"{R}_bench_same_command.json")
 json.dump(out, open(dst / "pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if not k.startswith("_") and not k.endswith("KiB")}, indent=1))
+print(json.dumps({k: (v["bytes_corrected"], v["sq"].get("SQ_INSTS_VALU")) for k, v in out["kernels"].items()}, indent=1))

@@ -291,7 +291,7 @@ def test_config_a_49_frames_through_the_cli(tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_onlybg"])
-def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode):
+def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode, nproc=2):
     """The multi-GPU path of the CLI (frames sharded over ranks, static cloud all-gathered or mean background
     all-reduced, frames gathered on rank 0) with two ranks.  This box has one GPU, so both ranks use it and the
     collectives go through gloo (--dist_backend gloo); everything else is the code an 8-GPU node runs.  The accumulated
@@ -308,8 +308,8 @@ def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode):
         argv += ["--fish_eye_rendering", "--use_mean_bg", "--only_bg", "--online_calibration_path", str(c["calib"])]
     rv.main(argv + ["--out_dir", str(tmp_path / "one")])
     script = Path(rv.__file__).resolve().parents[1] / "scripts" / "render_vipe_pointcloud.py"
-    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), *argv,
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29533 + nproc), str(script), *argv,
                           "--out_dir", str(tmp_path / "two"), "--dist_backend", "gloo"],
                          capture_output=True, text=True, timeout=240)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -323,6 +323,15 @@ def test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode):
     else:
         diff = np.abs(a.astype(int) - b.astype(int))
         assert diff.max() <= 2 and (diff > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_onlybg"])
+def test_cli_under_torchrun_with_eight_ranks_and_four_frames(clip_dir, tmp_path, mode):
+    """Eight ranks (the size of an MI355X node) for a clip of four frames: four ranks own a frame, four own nothing and
+    still take part in the all-gather of the static clouds / the all-reduce of the mean-background sums and in the final
+    gather of the frames.  All eight share this box's one GPU, collectives through gloo; same checks as with two ranks."""
+    assert clip_dir["F"] < 8
+    test_cli_under_torchrun_with_two_ranks(clip_dir, tmp_path, mode, nproc=8)
 
 
 @pytest.mark.parametrize("mode", ["accumulated_pinhole_dyn", "meanbg_fisheye_onlybg"])

@@ -111,3 +111,5 @@ extern "C" int egoprior_set_option(const char* name, int32_t value) {
         }
     return ep_host::fail(EGOPRIOR_E_INVALID, "unknown option");
 }
+
+extern "C" int32_t egoprior_get_option(const char* name) { return name == nullptr ? -1 : ep_host::option(name); }

@@ -261,10 +261,12 @@ struct SlicePlan {
     uint32_t* slot_base;   // n_tiles: first slot of a sliced tile, EP_NO_SLOT for the others
     uint32_t* done;        // n_tiles: slices of the tile that have finished (sliced tiles only)
     uint32_t* map;         // max_slots: tile | slice << 24 of every slot
-    uint32_t* total;       // [0]: slots in use this launch, [1]: the tail cut of this launch (see below)
-    unsigned long long* partial;  // max_slots x EP_K x 64 keys: the per-pixel lists of every slice, descending
-    uint32_t max_slots;    // 0: slicing is off
+    uint32_t* total;       // [0]: slots in use this launch, [1], [2]: the tail of this launch, a range of launch positions
+    unsigned long long* partial;  // (max_slots + 3 max_tail) x EP_K x 64 keys: the per-pixel lists of every slice, descending
+    uint32_t max_slots;    // slots for the slices of heavy tiles; 0 with max_tail == 0: slicing is off
     uint32_t wave_slots;   // waves of the splat kernel the GPU holds at once; 0: no tail slicing
+    uint32_t* tail_done;   // max_tail: slices of a tail tile that have finished
+    uint32_t max_tail;     // tiles the tail of a launch holds at most
 #ifdef EP_CHECK
     uint32_t nonce;        // differs from launch to launch (diagnostic build: seeds the hand-over checksums)
 #endif
@@ -296,13 +298,16 @@ __device__ __forceinline__ unsigned long long check_mix(unsigned long long h, un
 #define EP_SLOT_U64 (EP_K * 64)
 #endif
 // The tail of a launch.  When the tiles with real work (EP_TAIL_MIN entries or more) outnumber the wave slots of the GPU
-// and the last round of them would be less than three quarters full, that round would keep most of the GPU idle for the
-// duration of a whole tile.  k_tile_scan then picks a list length, the tail cut, such that the tiles from EP_TAIL_MIN
-// entries up to the cut are (about) the ones of that last round, and each of them is cut into EP_TAIL_SLICES slices.
+// and the last round of them would be at most half full, that round would keep most of the GPU idle for the duration of
+// a whole tile.  The launch order sorts the tiles by falling list length, so the tiles of that round are a range
+// [P0, P1) of launch positions: k_tile_scan only has to publish the two numbers (and to clear one completion counter
+// per tail tile).  The workgroup at position p of the range takes slice 0 of its tile, two workgroups right behind the
+// tiles of the grid take slices 1 and 2, and the three hand their lists over in slot 3 (p - P0) + slice of the slice area
+// like the slices of a heavy tile do.
 #define EP_TAIL_MIN 384u
 #define EP_TAIL_SLICES 3u
-__host__ __device__ __forceinline__ uint32_t slices_for(uint32_t count, uint32_t tail_cut) {
-    if (count <= 2u * EP_SLICE_LEN) return (count >= EP_TAIL_MIN && count <= tail_cut) ? EP_TAIL_SLICES : 1u;
+__host__ __device__ __forceinline__ uint32_t slices_for(uint32_t count) {  // heavy tiles
+    if (count <= 2u * EP_SLICE_LEN) return 1u;
     const uint32_t ns = (count + EP_SLICE_LEN - 1u) / EP_SLICE_LEN;
     return ns > EP_MAX_SLICES ? EP_MAX_SLICES : ns;
 }
@@ -321,14 +326,14 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t ohist[256];
-    __shared__ uint32_t want_s, cut_s, tail_tiles_s, slot_s;
+    __shared__ uint32_t want_s, p0_s, p1_s, slot_s;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     if (tid == 0) {
         carry_s = 0;
         want_s = 0;
-        cut_s = 0;
-        tail_tiles_s = 0;
+        p0_s = 0;
+        p1_s = 0;
         slot_s = 0;
     }
     if (tid < 256) ohist[tid] = 0u;
@@ -360,7 +365,7 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
             if (t0 + k < n_tiles) {
                 tile_start[t0 + k] = run;
                 tile_cursor[t0 + k] = 0u;
-                if (v[k] > 2u * EP_SLICE_LEN) want += slices_for(v[k], 0u);
+                if (v[k] > 2u * EP_SLICE_LEN) want += slices_for(v[k]);
                 atomicAdd(&ohist[255u - min(v[k] >> 4, 255u)], 1u);
             }
             run += v[k];
@@ -398,40 +403,37 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
         ohist[tid] = woff + incl - c;
     }
     __syncthreads();
-    // The tail cut (classes are 16 entries wide, class index 255 - length / 16: ohist[k] = tiles longer than class k's).
-    if (tid < 256 && sp.max_slots != 0u && sp.wave_slots != 0u) {
+    // The tail (classes are 16 entries wide, class index 255 - length / 16: ohist[k] = tiles longer than class k's = the
+    // launch position of class k's first tile).
+    if (tid < 256 && sp.max_tail != 0u && sp.wave_slots != 0u) {
         constexpr uint32_t k_min = 255u - EP_TAIL_MIN / 16u;  // the class of the shortest tiles that count as work
         const uint32_t n_long = ohist[k_min + 1u];
         const uint32_t rounds = n_long / sp.wave_slots;
         const uint32_t first_of_tail = rounds * sp.wave_slots;  // rank, longest first, of the first tile of the last round
         const uint32_t tail = n_long - first_of_tail;
-        if (rounds != 0u && tail != 0u && 4u * tail <= 3u * sp.wave_slots) {
+        if (rounds != 0u && tail != 0u && 2u * tail <= sp.wave_slots) {
             // the class that holds the tile of that rank (its longer members are cut too); not class 0, which holds every
-            // list of 4080 entries or more: the number of tail tiles must be exact, it decides whether the slots suffice
+            // list of 4080 entries or more
             const uint32_t mine_k = (uint32_t)tid;
             const bool here = mine_k >= 1u && mine_k <= k_min && ohist[mine_k] <= first_of_tail &&
                               first_of_tail < ohist[mine_k + 1u];
-            if (here) {
-                cut_s = ((255u - mine_k) << 4) + 15u;
-                tail_tiles_s = n_long - ohist[mine_k];
+            if (here && n_long - ohist[mine_k] <= sp.max_tail) {
+                p0_s = ohist[mine_k];
+                p1_s = n_long;
             }
         }
     }
     __syncthreads();
-    // heavy tiles all or nothing; the tail slices come on top when the slots allow
-    uint32_t want_all = (sp.max_slots != 0u) ? want_s : 0u, cut = cut_s;
-    if (want_all > sp.max_slots) {
-        want_all = 0u;
-        cut = 0u;
-    } else if (cut != 0u && want_all + EP_TAIL_SLICES * tail_tiles_s <= sp.max_slots) {
-        want_all += EP_TAIL_SLICES * tail_tiles_s;
-    } else {
-        cut = 0u;
-    }
+    const uint32_t tail_p0 = p0_s, tail_p1 = p1_s;
+    for (uint32_t q = (uint32_t)tid; q < tail_p1 - tail_p0; q += (uint32_t)NT) sp.tail_done[q] = 0u;
+    // heavy tiles all or nothing
+    uint32_t want_all = (sp.max_slots != 0u) ? want_s : 0u;
+    if (want_all > sp.max_slots) want_all = 0u;
     const bool slicing = want_all != 0u;
-    if (tid == 0 && sp.max_slots != 0u) {
+    if (tid == 0 && (sp.max_slots != 0u || sp.max_tail != 0u)) {
         sp.total[0] = want_all;  // (the per-tile slot words are only read when this says that there are slices)
-        sp.total[1] = cut;
+        sp.total[1] = tail_p0;
+        sp.total[2] = tail_p1;
     }
     // The launch order, and with it the slots of the sliced tiles: which slot a slice gets does not matter, so they are
     // handed out by a counter as the tiles come by.
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
             const uint32_t v = vv[k];
             tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
             if (slicing) {
-                const uint32_t ns = (want_s > sp.max_slots) ? 1u : slices_for(v, cut);
+                const uint32_t ns = slices_for(v);
                 uint32_t slot = EP_NO_SLOT;
                 if (ns > 1u) {
                     slot = atomicAdd(&slot_s, ns);
@@ -1005,18 +1007,37 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
 
     // The first workgroups of the launch take one tile each, longest list first, and leave the sliced tiles alone; the
     // sp.max_slots workgroups behind them take the slices (the slots in use come first, the others leave at once).
+    // ... and in front of those, 2 sp.max_tail workgroups for slices 1 and 2 of the launch's tail tiles (see EP_TAIL_MIN),
+    // whose slice 0 is taken by the tile's own workgroup.
     int tile;
     uint32_t my_slot = EP_NO_SLOT, n_slices = 1u, slice_no = 0u;
+    uint32_t tail_q = EP_NO_SLOT;  // this wave works on a slice of tail tile tail_q
     const uint32_t n_tiles_all = (uint32_t)(g.tiles_x * g.tiles_y);
-    if (blockIdx.x >= n_tiles_all) {
-        my_slot = blockIdx.x - n_tiles_all;
+    uint32_t tail_p0 = 0u, tail_p1 = 0u;
+    if (sp.max_tail != 0u) {
+        tail_p0 = sp.total[1];
+        tail_p1 = sp.total[2];
+    }
+    if (blockIdx.x >= n_tiles_all + 2u * sp.max_tail) {
+        my_slot = blockIdx.x - n_tiles_all - 2u * sp.max_tail;
         if (my_slot >= sp.total[0]) return;
         const uint32_t packed = sp.map[my_slot];
         tile = (int)(packed & 0xFFFFFFu);
         slice_no = packed >> 24;
+    } else if (blockIdx.x >= n_tiles_all) {
+        const uint32_t e = blockIdx.x - n_tiles_all;
+        tail_q = e >> 1;
+        if (tail_q >= tail_p1 - tail_p0) return;
+        tile = (int)tile_order[tail_p0 + tail_q];
+        slice_no = 1u + (e & 1u);
     } else {
         tile = (int)tile_order[blockIdx.x];
         if (sp.max_slots != 0u && sp.total[0] != 0u && sp.slot_base[tile] != EP_NO_SLOT) return;
+        if (blockIdx.x >= tail_p0 && blockIdx.x < tail_p1) tail_q = blockIdx.x - tail_p0;
+    }
+    if (tail_q != EP_NO_SLOT) {
+        n_slices = EP_TAIL_SLICES;
+        my_slot = sp.max_slots + EP_TAIL_SLICES * tail_q + slice_no;
     }
     const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
     const int lane = threadIdx.x;
@@ -1053,7 +1074,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     uint32_t pos = tile_start[tile], end = tile_start[tile + 1];
     if (my_slot != EP_NO_SLOT) {  // this wave's share of the list
         const uint32_t count = end - pos;
-        n_slices = slices_for(count, sp.total[1]);
+        if (tail_q == EP_NO_SLOT) n_slices = slices_for(count);
         const uint32_t span = slice_span(count, n_slices);
         pos = min(pos + slice_no * span, end);
         end = min(pos + span, end);
@@ -1737,7 +1758,8 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t before = 0u;
-        if (lane == 0) before = __hip_atomic_fetch_add(&sp.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* const done = (tail_q != EP_NO_SLOT) ? &sp.tail_done[tail_q] : &sp.done[tile];
+        if (lane == 0) before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         before = uniform_u32(before);
         if (before != n_slices - 1u) {
             EP_DIAG_FLUSH()
@@ -1749,7 +1771,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         // compute unit that the write-through hand-over has not been measured for.
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t first = sp.slot_base[tile];
+        const uint32_t first = (tail_q != EP_NO_SLOT) ? sp.max_slots + EP_TAIL_SLICES * tail_q : sp.slot_base[tile];
         for (uint32_t o = 0; o < n_slices; ++o) {
             if (first + o == my_slot) continue;
             const u64* const theirs = sp.partial + (size_t)(first + o) * EP_SLOT_U64 + lane;
@@ -1919,18 +1941,15 @@ struct RasterWs {
 
 // Slots that `entries` list entries can need at most: a sliced tile has more than 2 * EP_SLICE_LEN entries and takes
 // ceil(entries of the tile / EP_SLICE_LEN) slots, fewer than 1.5 slots per EP_SLICE_LEN entries.
-// ... plus the slices of a launch's tail: at most three quarters of the wave slots' worth of tiles, each of which holds
-// EP_TAIL_MIN entries or more.
 constexpr uint64_t kWaveSlots = 256 * 12;  // MI355X: 256 compute units, three splat waves on each of their four SIMDs
-uint64_t slice_slots_for(uint64_t entries) {
-    const uint64_t tail_tiles = std::min<uint64_t>(3 * kWaveSlots / 4, entries / EP_TAIL_MIN);
-    return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2 + EP_TAIL_SLICES * tail_tiles;
-}
+uint64_t heavy_slots_for(uint64_t entries) { return entries * 3 / (2 * (uint64_t)EP_SLICE_LEN) + 2; }
+// ... and the tail of a launch: at most half of the wave slots' worth of tiles, each of which holds EP_TAIL_MIN entries or more
+uint64_t tail_tiles_for(uint64_t entries) { return std::min<uint64_t>(kWaveSlots / 2, entries / EP_TAIL_MIN); }
 constexpr size_t kSlotBytes = (size_t)EP_SLOT_U64 * sizeof(unsigned long long);
 size_t slice_area_bytes(int n_tiles, uint64_t entries) {
-    const uint64_t slots = slice_slots_for(entries);
-    return (sizeof(uint32_t) * (2 * (size_t)n_tiles + 64) + 255) / 256 * 256 + (sizeof(uint32_t) * slots + 255) / 256 * 256 +
-           kSlotBytes * slots;
+    const uint64_t heavy = heavy_slots_for(entries), tail = tail_tiles_for(entries);
+    return (sizeof(uint32_t) * (2 * (size_t)n_tiles + 64) + 255) / 256 * 256 + (sizeof(uint32_t) * heavy + 255) / 256 * 256 +
+           (sizeof(uint32_t) * (tail + 1) + 255) / 256 * 256 + kSlotBytes * (heavy + EP_TAIL_SLICES * tail);
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -2004,7 +2023,7 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
                     hi = mid - 1;
             }
             cap = lo;
-            const uint64_t slots = slice_slots_for(cap);
+            const uint64_t slots = heavy_slots_for(cap), tail = tail_tiles_for(cap);
             char* q = (char*)ws + off + align_up((size_t)cap * sizeof(ep::ListEntry), 256);
             r.slices.slot_base = (uint32_t*)q;
             r.slices.done = r.slices.slot_base + n_tiles;
@@ -2012,9 +2031,12 @@ bool carve_raster_ws(void* ws, size_t bytes, int n_tiles, int64_t n, const Tunin
             q += align_up(sizeof(uint32_t) * (2 * (size_t)n_tiles + 64), 256);
             r.slices.map = (uint32_t*)q;
             q += align_up(sizeof(uint32_t) * slots, 256);
+            r.slices.tail_done = (uint32_t*)q;
+            q += align_up(sizeof(uint32_t) * (tail + 1), 256);
             r.slices.partial = (unsigned long long*)q;
             r.slices.max_slots = (uint32_t)(slots > 0x00FFFFFFull ? 0x00FFFFFFull : slots);
             r.slices.wave_slots = tn.tail_slots > 0 ? (uint32_t)tn.tail_slots : 0u;
+            r.slices.max_tail = r.slices.wave_slots != 0u ? (uint32_t)tail : 0u;
 #ifdef EP_CHECK
             static std::atomic<uint32_t> launch_nonce{1u};
             r.slices.nonce = launch_nonce.fetch_add(1u);
@@ -2115,7 +2137,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
         EP_LAUNCH("k_tile_fill", ep::k_tile_fill, dim3(bin_grid(n)), dim3(256), 0, s, g, d_ndc, n, d_n, w.tile_start,
                   w.tile_cursor, w.list, (uint32_t)w.capacity);
 #define EP_SWEEP(C_, NB_, WPE_)                                                                                \
-    EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles + w.slices.max_slots), dim3(64), 0, s, g, \
+    EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<C_, NB_, WPE_>), dim3(n_tiles + 2 * w.slices.max_tail + w.slices.max_slots), dim3(64), 0, s, g, \
               *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a, d_flags_b, w.slices, out)
     switch (tn.splat_variant) {
         case 1:  // plain register insertion: the simple cross-check
@@ -2137,7 +2159,7 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
 #ifdef EP_TILE_TIMES
 #define EP_PROBE_CASE(v_, stop_)                                                                                  \
     case v_:                                                                                                       \
-        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<448, 512, 3, EP_PIXMAJ, stop_>), dim3(n_tiles + w.slices.max_slots),    \
+        EP_LAUNCH("k_splat_sweep", (ep::k_splat_sweep<448, 512, 3, EP_PIXMAJ, stop_>), dim3(n_tiles + 2 * w.slices.max_tail + w.slices.max_slots),    \
                   dim3(64), 0, s, g, *rp, d_ndc, w.tile_start, w.tile_order, w.list, (uint32_t)w.capacity, d_flags_a,  \
                   d_flags_b, w.slices, out);                                                                         \
         break;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "egoprior_white_pixel_counts": (C.c_int, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "egoprior_postprocess_background": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "egoprior_set_option": (C.c_int, [C.c_char_p, _i32]),
+    "egoprior_get_option": (_i32, [C.c_char_p]),
     "egoprior_profile_begin": (C.c_int, []),
     "egoprior_profile_end": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _i32, _vp]),
 }
@@ -156,3 +157,7 @@ def profile_end() -> dict:
 
 def set_option(name: str, value: int) -> None:
     check(lib().egoprior_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    return int(lib().egoprior_get_option(name.encode()))

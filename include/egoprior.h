@@ -287,6 +287,8 @@ int egoprior_profile_begin(void);
  * MI355X): when the tiles with real work would leave the last round of a launch mostly empty, the tiles of that round
  * are cut into three slices each (shortens a lone launch for some views). */
 int egoprior_set_option(const char* name, int32_t value);
+/* current value of an option, -1 for a name the library does not know */
+int32_t egoprior_get_option(const char* name);
 int egoprior_profile_end(char* names, size_t names_bytes, float* total_ms, int32_t* calls, int32_t max_kernels,
                          int32_t* n_kernels);
 

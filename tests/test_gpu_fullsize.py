@@ -391,28 +391,7 @@ def test_fisheye_448_point_size_20_at_full_size(engine, scene):
     engine._ws.pop("render", None)
 
 
-def _check_build(engine):
-    """An Engine that calls the -DEP_CHECK build of the library (every slice hand-over of the splat kernel carries a
-    checksum which the merging wave verifies), or None when that build is not there."""
-    import copy
-    import ctypes as C
-    from egoprior import _lib
-    path = _lib.CSRC / "libegoprior_hip_check.so"
-    if not path.exists():
-        return None, None
-    L = C.CDLL(str(path))
-    for name, (rt, args) in _lib.SIGNATURES.items():
-        fn = getattr(L, name)
-        fn.restype, fn.argtypes = rt, args
-    L.egoprior_debug_check_counts.restype = C.c_int
-    L.egoprior_debug_check_counts.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]
-    E2 = copy.copy(engine)
-    E2.L = L
-    E2._ws = {}
-    return E2, L
-
-
-def test_accumulated_cloud_of_the_cli_default_mode(engine):
+def test_accumulated_cloud_of_the_cli_default_mode(engine, check_build):
     """What `python scripts/render_vipe_pointcloud.py` renders without --use_mean_bg: the static points of every frame of
     a clip accumulated into one cloud (scripts/render_vipe_pointcloud.py:304-456) -- 64 frames of 1080p at subsample 2,
     more than 30 M points, 64 near-copies of every surface point -- on the 448 x 448 fisheye image at point_size 5.  A few
@@ -465,14 +444,11 @@ def test_accumulated_cloud_of_the_cli_default_mode(engine):
     check(engine, 1)
     check(engine, 0)
     engine._ws.pop("raster", None)
-    E2, L2 = _check_build(engine)
-    if E2 is None:
-        pytest.skip("libegoprior_hip_check.so is not built (make -C egox-egopriorrenderer_amd/csrc libegoprior_hip_check.so)")
-    seen, failed = C.c_ulonglong(0), C.c_ulonglong(0)
-    assert L2.egoprior_debug_check_counts(C.byref(seen), C.byref(failed), 1) == 0
+    E2, L2 = check_build
+    E2.check_counts()
     for _ in range(3):  # the slot memory is reused from launch to launch: stale lists of the launch before must not pass
         check(E2, 1)
-    assert L2.egoprior_debug_check_counts(C.byref(seen), C.byref(failed), 1) == 0
-    print(f"slice hand-overs verified: {seen.value}, checksum mismatches: {failed.value}")
-    assert seen.value > 3 * 1000, seen.value   # a few hundred sliced tiles with dozens of slices each, three launches
-    assert failed.value == 0
+    seen, failed = E2.check_counts()
+    print(f"slice hand-overs verified: {seen}, checksum mismatches: {failed}")
+    assert seen > 3 * 1000, seen   # a few hundred sliced tiles with dozens of slices each, three launches
+    assert failed == 0

@@ -396,11 +396,12 @@ def test_rasterize_heavy_tiles_are_sliced(engine, mode, splat_variant):
         assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
 
 
-def test_rasterize_tail_tiles_are_sliced(engine):
-    """Option "tail_slots": when the tiles with real work outnumber the wave slots and the last round of them would be
-    mostly empty, the tiles of that round are cut into three slices each (the hand-over of the heavy tiles, for lists of a
-    few hundred entries).  64 tiles of 600 - 1400 entries with the option at 24 "slots": two full rounds and a tail of 16.
-    Same fragments and frame as the oracle's and as with the option off."""
+def test_rasterize_tail_tiles_are_sliced(engine, check_build):
+    """Option "tail_slots": when the tiles with real work outnumber the wave slots and the last round of them would be at
+    most half full, the tiles of that round are cut into three slices each (the hand-over of the heavy tiles, for lists of
+    a few hundred entries).  64 tiles of 600 - 1400 entries with the option at 28 "slots": two full rounds and a tail of 8;
+    at 50: one round and a tail of 14.  Same fragments and frame as the oracle's and as with the option off; the build
+    with hand-over checksums confirms that the slices really ran (two hand-overs per tail tile) and read what was written."""
     from egoprior import _lib, engine as eng
     H = W = 64
     ps = 2.5
@@ -416,15 +417,26 @@ def test_rasterize_tail_tiles_are_sliced(engine):
     ref_img = O.composite(ref_idx, ref_d, cols.astype(F32) / F32(255), r)
     rp = eng.make_raster_params(ps, H, W, K=20, colors_gt1=1)
     packed = pack_ndc(ndc, cols, engine.device)
-    for slots in (24, 40, 0):
+    default_slots = _lib.lib().egoprior_get_option(b"tail_slots")
+    for slots in (28, 50, 0):
         _lib.set_option("tail_slots", slots)
         try:
             res = engine.rasterize_composite(packed, None, rp, H, W, want_f32=True, want_fragments=True)
         finally:
-            _lib.set_option("tail_slots", 0)
+            _lib.set_option("tail_slots", default_slots)
         assert res["status"].item() == 0
         _check_fragments(res, ref_idx, ref_z, ref_d, 20)
         assert np.array_equal(res["image_f32"].cpu().numpy(), ref_img)
+    E2, L2 = check_build
+    for slots, lo, hi in ((28, 2 * 8, 2 * 16), (50, 2 * 14, 2 * 24), (0, 0, 0)):
+        L2.egoprior_set_option(b"tail_slots", slots)
+        E2.check_counts()
+        res = E2.rasterize_composite(packed, None, rp, H, W, want_f32=True, want_fragments=True)
+        torch.cuda.synchronize()
+        _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+        seen, failed = E2.check_counts()
+        # the tail is the last round's tiles plus the longer members of the length class it starts in
+        assert lo <= seen <= hi and failed == 0, (slots, seen, failed)
 
 
 def test_sliced_tiles_with_exact_and_short_workspaces(engine):

@@ -1273,6 +1273,7 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
         // use until the scatter.  Range c, which received cc records, is cut into 2^floor(log2 cc) equal sub-ranges, so
         // buckets hold a record or two wherever the keys are locally uniform, however unevenly the ranges are populated.
         uint32_t bq[RPL];
+        bool flat;          // (wave-uniform) no level-1 range holds more than EP_RANK_SELF records: level 1 is the bucket map
         {
             constexpr int LOGR = __builtin_ctz((unsigned)NB);
             static_assert(4 * NB <= 16 * C, "the level-1 table fits into S");
@@ -1291,6 +1292,20 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
             for (int u = 0; u < RPL; ++u)
                 if (val[u]) atomicAdd(&h1[(uint32_t)((key[u] - kmin) >> cshift)], 1u);
             __syncthreads();
+            {
+                uint32_t mx = 0u;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) mx = max(mx, h1[lane * PER + q]);
+                // Keys of one smooth surface spread evenly over the ranges (448 records in 512 ranges: a range with nine
+                // is a one-in-a-million event), and then the second level -- sub-range table, second histogram -- has
+                // nothing to add: the level-1 histogram is the bucket histogram.  Depth steps inside a tile take the
+                // two-level map below.
+                flat = __ballot(mx > (uint32_t)EP_RANK_SELF) == 0ull;
+            }
+            if (flat) {
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) bq[u] = val[u] ? (uint32_t)((key[u] - kmin) >> cshift) : 0u;
+            } else {
             {
                 uint32_t inf[PER];  // sub-ranges | log2(sub-ranges) << 16 of this lane's PER ranges
                 uint32_t sum = 0;
@@ -1325,20 +1340,24 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
                 const int fl = (int)(info >> 16);
                 bq[u] = val[u] ? (info & 0xFFFFu) + (uint32_t)((d - ((u64)c << cshift)) >> (cshift - fl)) : 0u;
             }
+            }  // two-level map
         }
 
         // ---- bucket: histogram, exclusive scan, scatter into S -----------------------------------------------------
+        if (!flat) {
 #pragma unroll
-        for (int u = 0; u < RPL; ++u)
-            if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
-        __syncthreads();
+            for (int u = 0; u < RPL; ++u)
+                if (val[u]) atomicAdd(&bkt[bq[u]], 1u);
+            __syncthreads();
+        }
         uint32_t bigmask = 0u;  // which of this lane's PER buckets hold more than EP_RANK_SELF records
         {
             uint32_t loc[PER];
             uint32_t sum = 0;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-                loc[q] = bkt[lane * PER + q];
+                // (flat: the level-1 counts are still where the histogram left them, in the first bytes of S)
+                loc[q] = flat ? reinterpret_cast<const uint32_t*>(S)[lane * PER + q] : bkt[lane * PER + q];
                 sum += loc[q];
                 bigmask |= (loc[q] > EP_RANK_SELF) ? (1u << q) : 0u;
             }

@@ -74,6 +74,12 @@ __device__ __forceinline__ void project_point(const egoprior_camera& c, float x,
 // lanes are grouped into runs of consecutive lanes with identical tile rectangles, and only the first lane of a run
 // touches the counters, adding the run's length.  Without it the same-address atomics of a wave serialise.  Must be
 // called by whole waves; lanes without a point pass live = false.
+// 2 or 3: every rectangle of the launch fits into that many tiles per axis; 0: larger ones can occur
+__device__ __forceinline__ int straight_span(const RasterGeom& g) {
+    const int m = g.span_x > g.span_y ? g.span_x : g.span_y;
+    return m <= 2 ? 2 : (m == 3 ? 3 : 0);
+}
+
 struct LaneRun {
     bool head;         // first lane of its run
     uint32_t len;      // run length (valid on the head)
@@ -94,10 +100,25 @@ __device__ __forceinline__ LaneRun lane_runs(bool live, int tx0, int tx1, int ty
     return r;
 }
 
+// The heads of the runs add their run's length to every tile of the rectangle.  When no rectangle of the launch is
+// larger than 2 x 2 or 3 x 3 tiles (`span`, the same for all threads), the candidates are visited in straight-line
+// code instead of per-lane loops.
+template <int SPAN>
+__device__ __forceinline__ void count_run_lds_span(const LaneRun& r, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                                   uint32_t* hist) {
+    const int t00 = ty0 * tiles_x + tx0;
+#pragma unroll
+    for (int q = 0; q < SPAN * SPAN; ++q) {
+        const int dx = q % SPAN, dy = q / SPAN;
+        const int t = t00 + dy * tiles_x + dx;
+        if (r.head && tx0 + dx <= tx1 && ty0 + dy <= ty1) atomicAdd(&hist[t >> 1], r.len << ((t & 1) * 16));
+    }
+}
 // Counting into a workgroup's LDS histogram: two 16-bit counters per word (a workgroup adds at most EP_BIN_PPB to a tile).
-__device__ __forceinline__ void count_point_lds(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                                uint32_t* hist) {
-    const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
+__device__ __forceinline__ void count_run_lds(const LaneRun& r, int span, int tx0, int tx1, int ty0, int ty1,
+                                              int tiles_x, uint32_t* hist) {
+    if (span == 2) return count_run_lds_span<2>(r, tx0, tx1, ty0, ty1, tiles_x, hist);
+    if (span == 3) return count_run_lds_span<3>(r, tx0, tx1, ty0, ty1, tiles_x, hist);
     if (!r.head) return;
     for (int ty = ty0; ty <= ty1; ++ty) {
         for (int tx = tx0; tx <= tx1; ++tx) {
@@ -108,9 +129,8 @@ __device__ __forceinline__ void count_point_lds(bool live, int tx0, int tx1, int
 }
 
 // Counting straight into the global per-tile counters: one atomic per run and tile.
-__device__ __forceinline__ void count_point_global(bool live, int tx0, int tx1, int ty0, int ty1, int tiles_x,
-                                                   uint32_t* __restrict__ tile_count) {
-    const LaneRun r = lane_runs(live, tx0, tx1, ty0, ty1);
+__device__ __forceinline__ void count_run_global(const LaneRun& r, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                                 uint32_t* __restrict__ tile_count) {
     if (!r.head) return;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[ty * tiles_x + tx], r.len);
@@ -169,6 +189,7 @@ __global__ void __launch_bounds__(256, 8) k_project_count(egoprior_camera cam, R
     if (blockIdx.x == 0 && threadIdx.x == 0 && d_total != nullptr) *d_total = (int32_t)n;
     if ((int64_t)blockIdx.x * EP_BIN_PPB >= n) return;  // the grid is sized for the capacity; the live count is smaller
     const int n_words = (n_tiles + 1) >> 1;
+    const int span = straight_span(g);
     if (LDS_AGG && do_count) {
         for (int t = threadIdx.x; t < n_words; t += blockDim.x) hist[t] = 0u;
         __syncthreads();
@@ -210,11 +231,12 @@ __global__ void __launch_bounds__(256, 8) k_project_count(egoprior_camera cam, R
             }
             if (do_count) {
                 int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-                const bool hit = live && tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1);
+                const bool hit = tile_range(g, ox, oy, oz, tx0, tx1, ty0, ty1) && live;
+                const LaneRun r = lane_runs(hit, tx0, tx1, ty0, ty1);
                 if (LDS_AGG)
-                    count_point_lds(hit, tx0, tx1, ty0, ty1, g.tiles_x, hist);
+                    count_run_lds(r, span, tx0, tx1, ty0, ty1, g.tiles_x, hist);
                 else
-                    count_point_global(hit, tx0, tx1, ty0, ty1, g.tiles_x, tile_count);
+                    count_run_global(r, tx0, tx1, ty0, ty1, g.tiles_x, tile_count);
             }
         }
     }
@@ -494,6 +516,42 @@ __global__ void __launch_bounds__(256) k_tile_fill(RasterGeom g, const egoprior_
     }
 }
 
+// One point per lane into the tiles of its rectangle, which takes at most SPAN x SPAN tiles: the candidates in
+// straight-line code; the heads' loads of all of them are in flight together (one branch, results used after it).
+template <int SPAN>
+__device__ __forceinline__ void fill_span(bool hit, const LaneRun& r, int tx0, int tx1, int ty0, int ty1, int tiles_x,
+                                          uint32_t within, ListEntry entry, const uint32_t* __restrict__ tile_start,
+                                          const uint32_t* __restrict__ mine, uint32_t* cur,
+                                          ListEntry* __restrict__ list, uint32_t capacity) {
+    constexpr int NQ = SPAN * SPAN;
+    const int t00 = ty0 * tiles_x + tx0;
+    bool in_q[NQ];
+    int t_q[NQ];
+    uint32_t slot0[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        in_q[q] = hit && tx0 + (q % SPAN) <= tx1 && ty0 + (q / SPAN) <= ty1;
+        t_q[q] = in_q[q] ? t00 + (q / SPAN) * tiles_x + (q % SPAN) : t00;
+        slot0[q] = 0u;
+    }
+    if (r.head) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) slot0[q] = tile_start[t_q[q]] + mine[t_q[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (in_q[q] && r.head) {
+            const uint32_t sh = (uint32_t)(t_q[q] & 1) * 16u;
+            slot0[q] += (atomicAdd(&cur[t_q[q] >> 1], r.len << sh) >> sh) & 0xFFFFu;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const uint32_t slot = (uint32_t)__shfl((int)slot0[q], r.head_lane) + within;
+        if (in_q[q] && slot < capacity) list[slot] = entry;
+    }
+}
+
 // The fill pass without global atomics.  The counting pass added every workgroup's per-tile counts to
 // the global counters and kept what those atomics returned (wg_piece): that is where the workgroup's entries start
 // inside each tile's list.  The same grid over the same points runs here, so a workgroup only has to hand out the slots
@@ -517,6 +575,7 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
     __syncthreads();
     const int64_t n_round = (n + EP_WAVE - 1) / EP_WAVE * EP_WAVE;
     const int lane = lane_id();
+    const int span = straight_span(g);
     for (int64_t base = (int64_t)blockIdx.x * EP_BIN_PPB; base < n_round; base += (int64_t)gridDim.x * EP_BIN_PPB) {
         egoprior_point pin[EP_BIN_PPT];
 #pragma unroll
@@ -529,21 +588,28 @@ __global__ void __launch_bounds__(256) k_tile_fill_pieces(RasterGeom g, const eg
         for (int k = 0; k < EP_BIN_PPT; ++k) {
             const int64_t i = base + k * 256 + threadIdx.x;
             int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
-            const bool hit = (i < n) && tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1);
+            const bool hit = tile_range(g, pin[k].x, pin[k].y, pin[k].z, tx0, tx1, ty0, ty1) && (i < n);
             const ListEntry entry = make_entry((uint32_t)i, pin[k].z);
             const LaneRun r = lane_runs(hit, tx0, tx1, ty0, ty1);
-            if (!hit) continue;
-            for (int ty = ty0; ty <= ty1; ++ty) {
-                for (int tx = tx0; tx <= tx1; ++tx) {
-                    const int t = ty * g.tiles_x + tx;
-                    uint32_t slot0 = 0u;
-                    if (r.head) {
-                        const uint32_t sh = (uint32_t)(t & 1) * 16u;
-                        slot0 = tile_start[t] + mine[t] + ((atomicAdd(&cur[t >> 1], r.len << sh) >> sh) & 0xFFFFu);
+            if (__ballot(hit) == 0ull) continue;
+            const uint32_t within = (uint32_t)(lane - r.head_lane);
+            if (span == 2) {
+                fill_span<2>(hit, r, tx0, tx1, ty0, ty1, g.tiles_x, within, entry, tile_start, mine, cur, list, capacity);
+            } else if (span == 3) {
+                fill_span<3>(hit, r, tx0, tx1, ty0, ty1, g.tiles_x, within, entry, tile_start, mine, cur, list, capacity);
+            } else if (hit) {
+                for (int ty = ty0; ty <= ty1; ++ty) {
+                    for (int tx = tx0; tx <= tx1; ++tx) {
+                        const int t = ty * g.tiles_x + tx;
+                        uint32_t slot0 = 0u;
+                        if (r.head) {
+                            const uint32_t sh = (uint32_t)(t & 1) * 16u;
+                            slot0 = tile_start[t] + mine[t] + ((atomicAdd(&cur[t >> 1], r.len << sh) >> sh) & 0xFFFFu);
+                        }
+                        // all lanes of a run walk the same rectangle, so the head is in this iteration too
+                        const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + within;
+                        if (slot < capacity) list[slot] = entry;
                     }
-                    // all lanes of a run walk the same rectangle, so the head is in this iteration too
-                    const uint32_t slot = (uint32_t)__shfl((int)slot0, r.head_lane) + (uint32_t)(lane - r.head_lane);
-                    if (slot < capacity) list[slot] = entry;
                 }
             }
         }
@@ -1906,17 +1972,16 @@ ep::RasterGeom make_geom(int H, int W, float radius) {
     g.rad_px_x = (float)((double)radius * (W / range_x) + 0.05);
     g.rad_px_y = (float)((double)radius * (H / range_y) + 0.05);
     g.radius2 = radius * radius;
+    // a disc's candidate pixels on one axis are the integers of an interval 2 * rad_px long
+    const double bx = std::ceil((2.0 * g.rad_px_x + 1.0) / EP_TILE) + 1.0;
+    const double by = std::ceil((2.0 * g.rad_px_y + 1.0) / EP_TILE) + 1.0;
+    g.span_x = (int)std::min<double>(bx, g.tiles_x);
+    g.span_y = (int)std::min<double>(by, g.tiles_y);
     return g;
 }
 
 // upper bound on tiles one disc can overlap
-int64_t tiles_per_point_bound(const ep::RasterGeom& g) {
-    const int64_t bx = (int64_t)std::ceil((2.0 * g.rad_px_x + 1.0) / EP_TILE) + 1;
-    const int64_t by = (int64_t)std::ceil((2.0 * g.rad_px_y + 1.0) / EP_TILE) + 1;
-    const int64_t bxc = bx < g.tiles_x ? bx : g.tiles_x;
-    const int64_t byc = by < g.tiles_y ? by : g.tiles_y;
-    return bxc * byc;
-}
+int64_t tiles_per_point_bound(const ep::RasterGeom& g) { return (int64_t)g.span_x * (int64_t)g.span_y; }
 
 // list positions are 32-bit: refuse a cloud whose discs could need more entries than that
 int check_list_size(const ep::RasterGeom& g, int64_t n) {

@@ -440,10 +440,12 @@ def run(args):
                                     "winners' records")
             wc, ga = sq.get("SQ_WAVE_CYCLES"), sq.get("GRBM_GUI_ACTIVE")
             if wc and ga:
-                # wave-cycles (units of 4 clocks) over the kernel's busy clocks = waves resident on average; the kernel
-                # runs 3 waves per SIMD, 3072 on the chip
-                roofline["resident_waves_avg"] = round(4.0 * wc / ga, 1)
-                roofline["occupancy"] = round(4.0 * wc / ga / 3072.0, 3)
+                # wave-cycles (units of 4 clocks) over the kernel's busy clocks = waves resident on average; the counter file
+                # holds GRBM_GUI_ACTIVE summed over the 8 XCDs (it comes to 8 x duration x 2.4 GHz); the kernel runs 3
+                # waves per SIMD, 3072 on the chip
+                busy_clocks = ga / 8.0
+                roofline["resident_waves_avg"] = round(4.0 * wc / busy_clocks, 1)
+                roofline["occupancy"] = round(4.0 * wc / busy_clocks / 3072.0, 3)
             if ldsc.get("SQ_LDS_IDX_ACTIVE"):
                 roofline["lds_conflict_frac"] = round(ldsc.get("SQ_LDS_BANK_CONFLICT", 0) / ldsc["SQ_LDS_IDX_ACTIVE"], 3)
 

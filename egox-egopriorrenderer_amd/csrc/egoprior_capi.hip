@@ -87,6 +87,7 @@ Opt g_opts[] = {
     {"bin_lds", 1},        // 1: tile counts aggregated per workgroup in LDS, 0: straight global atomics
     {"slices", 1},         // 1: tiles with very long lists are split over several waves, 0: one wave per tile always
     {"scan_threads", 256},  // workgroup size of the tile scan: 256 or 1024
+    {"scan_once", 1},       // 1: grids of up to 8192 tiles are scanned from registers after one round of loads, 0: always the looping scan
     {"tail_slots", 0},      // > 0: the number of splat waves the GPU holds at once (3072 on MI355X: 256 compute units x
                             // 12); when the tiles with real work would leave the last round of a launch mostly empty,
                             // the tiles of that round are cut into three slices each.  Off by default: it shortens a

@@ -338,13 +338,15 @@ __host__ __device__ __forceinline__ uint32_t slice_span(uint32_t count, uint32_t
     return (((count + ns - 1u) / ns) + 63u) & ~63u;
 }
 
-template <int NT>
+// ONCE: the grid has at most NT * PT tiles; every thread then holds the counts of its PT consecutive tiles in registers
+// from one round of loads to the end of the kernel (a single workgroup waits out every memory round trip it makes: the
+// looping form makes eight of them at 6 240 tiles, this one makes one).
+template <int NT, int PT = 8, bool ONCE = false>
 __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ tile_count,
                                                     uint32_t* __restrict__ tile_start,
                                                     uint32_t* __restrict__ tile_cursor,
                                                     uint32_t* __restrict__ tile_order, int n_tiles, uint32_t capacity,
                                                     int32_t* __restrict__ d_status, SlicePlan sp) {
-    constexpr int PT = 8;  // tiles per thread and pass
     __shared__ uint32_t wave_sums[16];
     __shared__ uint32_t carry_s;
     __shared__ uint32_t ohist[256];
@@ -361,15 +363,26 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     if (tid < 256) ohist[tid] = 0u;
     __syncthreads();
     uint32_t want = 0;  // slots the heavy tiles among this thread's tiles would take
+    uint32_t v[PT];
     for (int base = 0; base < n_tiles; base += NT * PT) {
         const int t0 = base + tid * PT;
-        uint32_t v[PT];
         uint32_t sum = 0;
+        if (ONCE && t0 + PT <= n_tiles) {
+            // (the counters start at the 256-byte-aligned base of the workspace)
 #pragma unroll
-        for (int k = 0; k < PT; ++k) {
-            v[k] = (t0 + k < n_tiles) ? tile_count[t0 + k] : 0u;
-            sum += v[k];
+            for (int k = 0; k < PT; k += 4) {
+                const uint4 q = *reinterpret_cast<const uint4*>(tile_count + t0 + k);
+                v[k] = q.x;
+                v[k + 1] = q.y;
+                v[k + 2] = q.z;
+                v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PT; ++k) v[k] = (t0 + k < n_tiles) ? tile_count[t0 + k] : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) sum += v[k];
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -460,21 +473,21 @@ __global__ void __launch_bounds__(NT) k_tile_scan(const uint32_t* __restrict__ t
     // The launch order, and with it the slots of the sliced tiles: which slot a slice gets does not matter, so they are
     // handed out by a counter as the tiles come by.
     // (eight counts are requested per trip: one at a time, every trip of this single workgroup waited out a memory round trip)
-    for (int t0 = tid; t0 < n_tiles; t0 += NT * PT) {
+    for (int t0 = ONCE ? tid * PT : tid; t0 < n_tiles; t0 += NT * PT) {
         uint32_t vv[PT];
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
-            const int t = t0 + k * NT;
-            vv[k] = tile_count[t < n_tiles ? t : n_tiles - 1];
+            const int t = ONCE ? t0 + k : t0 + k * NT;
+            vv[k] = ONCE ? v[k] : tile_count[t < n_tiles ? t : n_tiles - 1];
         }
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
-            const int t = t0 + k * NT;
+            const int t = ONCE ? t0 + k : t0 + k * NT;
             if (t >= n_tiles) break;
-            const uint32_t v = vv[k];
-            tile_order[atomicAdd(&ohist[255u - min(v >> 4, 255u)], 1u)] = (uint32_t)t;
+            const uint32_t vk = vv[k];
+            tile_order[atomicAdd(&ohist[255u - min(vk >> 4, 255u)], 1u)] = (uint32_t)t;
             if (slicing) {
-                const uint32_t ns = slices_for(v);
+                const uint32_t ns = slices_for(vk);
                 uint32_t slot = EP_NO_SLOT;
                 if (ns > 1u) {
                     slot = atomicAdd(&slot_s, ns);
@@ -1993,7 +2006,7 @@ int check_list_size(const ep::RasterGeom& g, int64_t n) {
 // The tuning switches a call works with, read once when the call starts (egoprior_set_option may change them from
 // another thread at any time; a call in progress keeps the values it started with).
 struct Tuning {
-    int splat_variant, fill_pieces, bin_lds, slices, scan_threads, tail_slots;
+    int splat_variant, fill_pieces, bin_lds, slices, scan_threads, scan_once, tail_slots;
 };
 Tuning read_tuning() {
     Tuning t;
@@ -2002,6 +2015,7 @@ Tuning read_tuning() {
     t.bin_lds = ep_host::option("bin_lds");
     t.slices = ep_host::option("slices");
     t.scan_threads = ep_host::option("scan_threads");
+    t.scan_once = ep_host::option("scan_once");
     t.tail_slots = ep_host::option("tail_slots");
     return t;
 }
@@ -2207,7 +2221,13 @@ int launch_scan_fill_splat(const ep::RasterGeom& g, const egoprior_raster_params
     const int n_tiles = g.tiles_x * g.tiles_y;
     // 256 threads (one wave per SIMD, 62 VGPRs) find room on a compute unit whose SIMDs are full of the splat waves of the
     // frames in flight; 1024 threads are 3 us faster on an idle GPU (option "scan_threads")
-    if (tn.scan_threads != 1024)
+    if (tn.scan_threads != 1024 && n_tiles <= 256 * 16 && tn.scan_once != 0)
+        EP_LAUNCH("k_tile_scan", (ep::k_tile_scan<256, 16, true>), dim3(1), dim3(256), 0, s, w.tile_count, w.tile_start,
+                  w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
+    else if (tn.scan_threads != 1024 && n_tiles <= 256 * 32 && tn.scan_once != 0)
+        EP_LAUNCH("k_tile_scan", (ep::k_tile_scan<256, 32, true>), dim3(1), dim3(256), 0, s, w.tile_count, w.tile_start,
+                  w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
+    else if (tn.scan_threads != 1024)
         EP_LAUNCH("k_tile_scan", ep::k_tile_scan<256>, dim3(1), dim3(256), 0, s, w.tile_count, w.tile_start,
                   w.tile_cursor, w.tile_order, n_tiles, (uint32_t)w.capacity, d_status, w.slices);
     else

@@ -197,12 +197,16 @@ def splat_variant(request):
     _lib.set_option("splat_variant", 0)
 
 
-@pytest.fixture(params=[1, 0], ids=["count-lds", "count-global"])
+@pytest.fixture(params=[(1, 1), (0, 1), (1, 0)], ids=["count-lds", "count-global", "scan-loop"])
 def bin_variant(request):
+    """Counting aggregated in LDS (default) or straight on the global counters; the tile scan from registers after one
+    round of loads (default) or in its looping form."""
     from egoprior import _lib
-    _lib.set_option("bin_lds", request.param)
+    _lib.set_option("bin_lds", request.param[0])
+    _lib.set_option("scan_once", request.param[1])
     yield request.param
     _lib.set_option("bin_lds", 1)
+    _lib.set_option("scan_once", 1)
 
 
 def _check_fragments(res, ref_idx, ref_z, ref_d, K):

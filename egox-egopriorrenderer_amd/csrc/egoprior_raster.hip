@@ -1173,18 +1173,21 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
     unsigned long long dbg_g[5] = {0, 0, 0, 0, 0}, dbg_m[4] = {0, 0, 0, 0}, dbg_s[6] = {0, 0, 0, 0, 0, 0};
 #endif
 
-    // Per-record threshold tables (rebuilt after every merge, read while the next chunk is gathered; they live in `aux`,
-    // which is free between a merge and the next bucket count): rowband[a * 8 + b] is the largest K-th key over the pixel
-    // rows a..b of the tile (all ones while a pixel's list is not full), colband the same for columns.  A record can
-    // only enter the list of a pixel its disc reaches, and min(rowband[rows it reaches], colband[columns it reaches]) is
-    // an upper bound on the K-th keys of those pixels.
-    // The tables have LDS of their own (1.1 KiB), so that they outlive the chunk after the one they were built for: a
-    // pixel's K-th key only ever falls, which keeps an old table a valid bound, and the tables of a long list change
-    // little from chunk to chunk.  They are rebuilt after chunks 2, 3, 4, 6, 8, 12, 16, 24, 32, ... (building them is two
-    // wave-wide reductions, two barriers and a short divergent loop: as much as gathering a batch of keys).
-    __shared__ u64 band_tables[2 * 64 + 16];
-    u64* const rowband = band_tables;
-    u64* const colband = rowband + 64;
+    // Per-record threshold tables (read while a chunk is gathered): rowband[band(a, b)] is the largest K-th key over the
+    // pixel rows a..b of the tile (all ones while a pixel's list is not full), colband the same for columns a..b.  A
+    // record can only enter the list of a pixel its disc reaches, and min(rowband[rows it reaches], colband[columns it
+    // reaches]) is an upper bound on the K-th keys of those pixels.
+    // The tables have LDS of their own, so that they outlive the chunk after the one they were built for: a pixel's K-th
+    // key only ever falls, which keeps an old table a valid bound, and the tables of a long list change little from chunk
+    // to chunk.  They are rebuilt after chunks 2, 3, 4, 6, 8, 12, 16, 24, 32, ... (building them is two wave-wide
+    // reductions, two barriers and a short divergent loop: as much as gathering a batch of keys).
+    // They are kept small: only the 36 bands with a <= b are stored, and the column table holds the depth bits of its
+    // keys only (a record then passes on equal depth whatever its index: still a bound).  With that the default kernel
+    // stays within 11 KiB of LDS, and twelve waves of it leave a compute unit room for two workgroups of the binning
+    // kernels instead of one (LDS is handed out in steps of 512 bytes).
+    __shared__ u64 rowband[36];
+    __shared__ uint32_t colband[36];
+    auto band = [](int a_, int b_) { return ((a_ * (17 - a_)) >> 1) + b_ - a_; };  // a_ <= b_ < 8
     const float inv_pitch = uniform_f32(0.5f * (float)min(g.W, g.H));           // pixels per NDC unit
     const float reach_px = uniform_f32(sqrtf(r2) * inv_pitch + 0.01f);          // the margin covers every rounding
 
@@ -1241,8 +1244,9 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
                     const int xa = max((int)ceilf(colf - reach_px), 0), xb = min((int)floorf(colf + reach_px), 7);
                     const int ya = max((int)ceilf(rowf - reach_px), 0), yb = min((int)floorf(rowf + reach_px), 7);
                     o = o && xa <= xb && ya <= yb;
-                    const u64 tr = rowband[o ? ya * 8 + yb : 0], tc = colband[o ? xa * 8 + xb : 0];
-                    o = o && k[u] < (tr < tc ? tr : tc);
+                    const u64 tr = rowband[o ? band(ya, yb) : 0];
+                    const uint32_t tc = colband[o ? band(xa, xb) : 0];
+                    o = o && k[u] < tr && (uint32_t)(k[u] >> 32) <= tc;
                 }
                 ok[u] = o;
                 s += __popcll(__ballot(o));
@@ -1812,8 +1816,8 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
                 const u64 o = __shfl_xor(cmax, d);
                 cmax = o > cmax ? o : cmax;
             }
-            u64* const line = colband + 64;  // 8 row maxima, 8 column maxima
-            __syncthreads();                 // (the tables' last readers, the previous gather, are long done)
+            u64* const line = reinterpret_cast<u64*>(aux);  // 8 row maxima, 8 column maxima (the hit masks are dead)
+            __syncthreads();                                // (the tables' last readers, the previous gather, are long done)
             if ((lane & 7) == 0) line[lane >> 3] = rmax;
             if (lane < 8) line[8 + lane] = cmax;
             __syncthreads();
@@ -1823,8 +1827,10 @@ __device__ __forceinline__ void splat_sweep_wave(const RasterGeom& g, const egop
                 rb = a > rb ? a : rb;
                 cb = b > cb ? b : cb;
             }
-            rowband[lane] = rb;
-            colband[lane] = cb;
+            if ((lane >> 3) <= (lane & 7)) {
+                rowband[band(lane >> 3, lane & 7)] = rb;
+                colband[band(lane >> 3, lane & 7)] = (uint32_t)(cb >> 32);
+            }
         }
         EP_MSTAGE(3)
 #undef EP_MSTAGE

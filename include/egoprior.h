@@ -283,7 +283,8 @@ int egoprior_profile_begin(void);
  * aggregated per workgroup in LDS, 0: straight global atomics.  "slices": 1 default: tiles with more than 32768 list
  * entries are split over several waves, 0: one wave per tile always.  "scan_threads": 256 default, or 1024: workgroup
  * size of the single-workgroup tile scan (256 threads find room on a compute unit that is full of splat waves; 1024 are
- * 3 us faster on an idle GPU).  "tail_slots": 0 default; > 0 = the number of splat waves the GPU holds at once (3072 on
+ * 3 us faster on an idle GPU).  "scan_once": 1 default: grids of up to 8192 tiles are scanned from registers after one
+ * round of loads, 0: always the looping scan.  "tail_slots": 0 default; > 0 = the number of splat waves the GPU holds at once (3072 on
  * MI355X): when the tiles with real work would leave the last round of a launch mostly empty, the tiles of that round
  * are cut into three slices each (shortens a lone launch for some views). */
 int egoprior_set_option(const char* name, int32_t value);

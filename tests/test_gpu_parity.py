@@ -328,6 +328,30 @@ def test_rasterize_discs_that_touch_pixel_centres_exactly(engine, size, ps, spla
     _check_fragments(res, ref_idx, ref_z, ref_d, 20)
 
 
+@pytest.mark.parametrize("size", [(8, 8), (8, 16), (24, 8), (16, 16), (9, 17)])
+@pytest.mark.parametrize("ps", [1.0, 3.0, 6.0, 11.0])
+def test_rasterize_on_grids_narrower_than_a_disc(engine, size, ps, bin_variant):
+    """Images of one to three tiles per axis, where the most tiles a disc can take on an axis is cut off by the grid: the
+    binning's straight-line walks (rectangles of at most 2 x 2 and 3 x 3 tiles) and its per-lane loops all see rectangles
+    that the image border clips, and candidate tiles beyond the last row or column must never be touched."""
+    from egoprior import engine as eng
+    He, We = size
+    rng = np.random.default_rng(He * 100 + We + int(ps * 10))
+    n = 3000
+    ndc = np.empty((n, 3), dtype=F32)
+    ndc[:, 0] = rng.uniform(-1.6, 1.6, n) * (We / min(He, We))
+    ndc[:, 1] = rng.uniform(-1.6, 1.6, n) * (He / min(He, We))
+    ndc[:, 2] = rng.uniform(0.5, 4.0, n)
+    cols = rng.integers(2, 256, size=(n, 3), dtype=np.uint8)
+    r = F32(O.radius_ndc(ps, He, We))
+    ref_idx, ref_z, ref_d = O.rasterize(ndc, r, He, We, 20, "scatter")
+    assert (ref_idx >= 0).any()
+    rp = eng.make_raster_params(ps, He, We, K=20, colors_gt1=1)
+    res = engine.rasterize_composite(pack_ndc(ndc, cols, engine.device), None, rp, He, We, want_fragments=True)
+    assert res["status"].item() == 0
+    _check_fragments(res, ref_idx, ref_z, ref_d, 20)
+
+
 @pytest.mark.parametrize("mode", ["narrow_band", "one_depth_plus_outliers", "few_depths"])
 def test_rasterize_clustered_depths(engine, mode, splat_variant):
     """Depth distributions that defeat equal-width bucketing: a narrow band of depths next to a wide spread, one single

@@ -4,6 +4,8 @@ Tolerances (the bar): index maps, validity masks, point counts/order, colours an
 floating-point outputs are compared bit-exact too wherever the oracle fixes the operation order (everything except the
 fisheye projection, whose atan differs between libm and the GPU math library: 1e-5 relative there).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -515,7 +517,8 @@ def test_sliced_tiles_with_exact_and_short_workspaces(engine):
     assert np.array_equal(zb[hit], ndc[idx[hit], 2])            # ... with their own depths
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+# EGOPRIOR_FUZZ_SEEDS=n runs n random geometries instead of 16 (a soak run for kernel changes)
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("EGOPRIOR_FUZZ_SEEDS", "16")))))
 def test_rasterize_random_geometry(engine, seed):
     """Random image sizes (ragged last tiles), point sizes from sub-pixel to a quarter of the image, K of 1, 5 or 20,
     and clouds that mix a uniform spread with a tight blob (every fourth seed: a blob dense enough for its tiles to be

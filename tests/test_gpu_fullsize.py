@@ -8,6 +8,8 @@ take a minute per frame.  Instead of the oracle, these use properties that do no
   no fused multiply-add) finds exactly the same K indices in the same order;
 * rendering twice gives the same bits (the tile lists are filled with atomics in a different order every time).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -446,9 +448,10 @@ def test_accumulated_cloud_of_the_cli_default_mode(engine, check_build):
     engine._ws.pop("raster", None)
     E2, L2 = check_build
     E2.check_counts()
-    for _ in range(3):  # the slot memory is reused from launch to launch: stale lists of the launch before must not pass
+    launches = int(os.environ.get("EGOPRIOR_HANDOVER_LAUNCHES", "3"))  # more for a soak run
+    for _ in range(launches):  # the slot memory is reused from launch to launch: stale lists of the launch before must not pass
         check(E2, 1)
     seen, failed = E2.check_counts()
     print(f"slice hand-overs verified: {seen}, checksum mismatches: {failed}")
-    assert seen > 3 * 1000, seen   # a few hundred sliced tiles with dozens of slices each, three launches
+    assert seen > launches * 1000, seen   # a few hundred sliced tiles with dozens of slices each, per launch
     assert failed == 0

@@ -54,6 +54,13 @@ with tempfile.TemporaryDirectory() as tmp:
     rv.main(argv)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    # with EGOPRIOR_LIB=libegoprior_hip_check.so: how many slice hand-overs the runs above verified (four frames in flight)
+    from egoprior import _lib
+    if hasattr(_lib.lib(), "egoprior_debug_check_counts"):
+        import ctypes
+        seen, failed = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        _lib.lib().egoprior_debug_check_counts(ctypes.byref(seen), ctypes.byref(failed), 0)
+        print(f"slice hand-overs verified: {seen.value}, checksum mismatches: {failed.value}", flush=True)
     if ref is not None and "--compare-streamed" in sys.argv:
         import os
         os.environ["EGOPRIOR_STREAM_CLIP"] = "1"
